@@ -1,0 +1,271 @@
+"""TEST INFRASTRUCTURE ONLY.  Run where the reference is mounted (needs oracle/_ref/librt_ref.so):
+
+    make -C oracle && python oracle/make_golden.py
+
+1. Validates every function of the CPU restatement (librt_oracle.so) bit-for-bit against the
+   compiled, untouched reference on seeded inputs.
+2. Writes the golden vectors (inputs + the reference's outputs) to tests/golden/*.npz and copies
+   the reference's data files (meshes, texture bitmap -- data, not source) to tests/golden/data/,
+   so that every check can be repeated where the reference is not mounted.
+"""
+import hashlib
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle.bindings import Oracle, Reference, id_map_hash  # noqa: E402
+
+REF_DIR = os.environ.get("REF_DIR", "/root/reference")
+GOLD = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(GOLD, "data")
+CAM = np.array([2.8, 0, 0, 0, 0, 0.0])   # main.cpp:626-628
+failures = []
+
+
+def check(name, a, b):
+    a = np.asarray(a); b = np.asarray(b)
+    same = a.shape == b.shape and np.array_equal(a, b, equal_nan=True)
+    print(("ok   " if same else "FAIL ") + name)
+    if not same:
+        failures.append(name)
+        if a.shape == b.shape:
+            bad = np.flatnonzero(~((a == b) | (np.isnan(a.astype(float)) & np.isnan(b.astype(float)))).ravel())
+            print("     first mismatches:", bad[:5], a.ravel()[bad[:5]], b.ravel()[bad[:5]])
+
+
+def build_scene(api, mesh, rgbs=(0.5, 0.5, 0.5, 0.0), ior=1.0, off=(0, 0, 0), cornell=True):
+    if mesh:
+        ok = api.load_obj(os.path.join(DATA, mesh), rgbs, ior, off)
+        assert ok == 1, mesh
+    if cornell:
+        api.add_cornell()
+    api.build_bvh()
+
+
+def main():
+    os.makedirs(DATA, exist_ok=True)
+    for f in ["teapot_normal.obj", "water.obj", "teapot1.obj", "test.obj", "tex.bmp"]:
+        shutil.copyfile(os.path.join(REF_DIR, f), os.path.join(DATA, f))
+    rng = np.random.default_rng(20240611)
+
+    # ---------------------------------------------------------------- G2/G3/G1: BVH + primary hits
+    hashes = {}
+    for mesh in ["teapot_normal.obj", "water.obj"]:
+        ref = Reference(); orc = Oracle()
+        build_scene(ref, mesh); build_scene(orc, mesh)
+        tag = mesh.split(".")[0]
+        r_rec, r_box = ref.bvh_dump(); o_rec, o_box = orc.bvh_dump()
+        check(f"bvh topology {tag}", r_rec, o_rec)
+        check(f"bvh boxes {tag}", r_box, o_box)
+        np.savez_compressed(os.path.join(GOLD, f"bvh_{tag}.npz"), rec=r_rec, boxes=r_box)
+        w, h = 1920, 1080
+        r_org, r_dir = ref.primary_rays(w, h, CAM); o_org, o_dir = orc.primary_rays(w, h, CAM)
+        check(f"primary rays {tag}", r_dir, o_dir)
+        r_ids, r_t = ref.shoot(r_org, r_dir); o_ids, o_t = orc.shoot_mt(o_org, o_dir)
+        check(f"hit ids 1920x1080 {tag}", r_ids, o_ids)
+        check(f"hit t 1920x1080 {tag}", r_t, o_t)
+        nmesh = ref.size() - 10
+        hashes[tag] = dict(hash=id_map_hash(r_ids), hits=int((r_ids >= 0).sum()), mesh_hits=int(((r_ids >= 0) & (r_ids < nmesh)).sum()),
+                           t_sha256=hashlib.sha256(r_t.tobytes()).hexdigest())
+        print("    ", tag, hashes[tag])
+        # G1: small full dump
+        for (sw, sh) in [(64, 64), (96, 54), (40, 72)]:
+            org, d = ref.primary_rays(sw, sh, CAM)
+            ids, t = ref.shoot(org, d)
+            oi, ot = orc.shoot(org, d)
+            check(f"hit ids/t {sw}x{sh} {tag}", np.c_[ids, t], np.c_[oi, ot])
+            np.savez_compressed(os.path.join(GOLD, f"hits_{tag}_{sw}x{sh}.npz"), cam=CAM, w=sw, h=sh, org=org[:1], dir=d, ids=ids, t=t)
+        # random rays in the self-test style (BVH.cpp:223-227: origin and unnormalised direction in [-1,1]^3)
+        n = 20000
+        org = rng.uniform(-1, 1, (n, 3)); d = rng.uniform(-1, 1, (n, 3))
+        ids, t = ref.shoot(org, d); oi, ot = orc.shoot(org, d)
+        check(f"random-ray ids/t {tag}", np.c_[ids, t], np.c_[oi, ot])
+        # bounded range (the SSS probe passes d = 0.005, main.cpp:584) and mid ranges
+        md = rng.choice([0.005, 0.05, 0.5, 2.0], n)
+        ids2, t2 = ref.shoot(org, d, md); oi2, ot2 = orc.shoot(org, d, md)
+        check(f"bounded-range ids/t {tag}", np.c_[ids2, t2], np.c_[oi2, ot2])
+        # axis-parallel rays: zero direction components exercise the inf/NaN paths of BBox::Intersect
+        dz = d.copy(); dz[np.arange(n), rng.integers(0, 3, n)] = 0.0
+        dz[: n // 4, rng.integers(0, 3)] = 0.0
+        oz = org.copy(); oz[: n // 8] = np.round(oz[: n // 8] * 4) / 4
+        ids3, t3 = ref.shoot(oz, dz); oi3, ot3 = orc.shoot(oz, dz)
+        check(f"axis-parallel ids/t {tag}", np.c_[ids3, t3], np.c_[oi3, ot3])
+        np.savez_compressed(os.path.join(GOLD, f"rays_{tag}.npz"), org=org, dir=d, ids=ids, t=t, max_dist=md, ids_bounded=ids2,
+                            t_bounded=t2, org_axis=oz, dir_axis=dz, ids_axis=ids3, t_axis=t3)
+    with open(os.path.join(GOLD, "idmap_hashes.txt"), "w") as f:
+        for k, v in hashes.items():
+            f.write(f"{k} {v['hash']} {v['hits']} {v['mesh_hits']} {v['t_sha256']}\n")
+
+    # ---------------------------------------------------------------- G4: primitive vectors
+    ref = Reference(); orc = Oracle()
+    tris = []
+    for api in (ref, orc):
+        r2 = np.random.default_rng(7)
+        for i in range(24):
+            scale = [1.0, 0.1, 0.01, 3.0][i % 4]
+            A, C, B = r2.uniform(-1, 1, (3, 3)) * scale
+            api.add_triangle(A, C, B, (0.3, 0.6, 0.9, 0.0), 1.5)
+            if api is ref:
+                tris.append((A, C, B))
+        api.add_triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), (1, 1, 1, 0), 1.0)      # axis aligned
+        api.add_triangle((0, 0, 0), (0, 0, 1), (0, 1, 0), (1, 1, 1, 0), 1.0)      # degenerate cascade branch 1
+        api.add_triangle((0, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 1, 0), 1.0)
+        api.add_triangle((1, 1, 1), (1, 1, 2), (2, 1, 1), (1, 1, 1, 0), 1.0)      # AB_y = AC_y = 0
+        for i in range(6):
+            api.add_sphere(r2.uniform(-0.5, 0.5, 3), [0.3, 0.05, 1.0][i % 3], (1, 1, 1, 0.9), 1.5)
+    nprim = ref.size()
+    n = 1500
+    org = rng.uniform(-1.5, 1.5, (n, 3)); tgt = rng.uniform(-0.6, 0.6, (n, 3))
+    d = tgt - org; d /= np.linalg.norm(d, axis=1)[:, None]
+    d[::7] = rng.uniform(-1, 1, (len(d[::7]), 3))     # unnormalised
+    d[::11, 0] = 0.0
+    t_all = np.zeros((nprim, n))
+    for o in range(nprim):
+        rt = ref.obj_intersect(o, org, d); ot = orc.obj_intersect(o, org, d)
+        t_all[o] = rt
+        if not np.array_equal(rt, ot, equal_nan=True):
+            failures.append(f"prim {o}")
+            print("FAIL prim", o)
+    print("ok   primitive intersections" if not any(f.startswith("prim") for f in failures) else "FAIL primitive intersections")
+    boxes = np.array([ref.obj_bbox(o) for o in range(nprim)])
+    check("primitive bboxes", boxes, np.array([orc.obj_bbox(o) for o in range(nprim)]))
+    best = rng.choice([1e9, 3.0, 1.0, 0.3], n)
+    bt = np.array([ref.bbox_intersect(boxes[o], org, d, best) for o in range(nprim)])
+    bo = np.array([orc.bbox_intersect(boxes[o], org, d, best) for o in range(nprim)])
+    check("bbox slab test", bt, bo)
+    # zero-direction components with origins on slab planes -> 0*inf NaN paths
+    ob = org.copy(); db = d.copy()
+    ob[:200, 0] = boxes[0, 0]; db[:200, 0] = 0.0
+    ob[200:400, 1] = boxes[1, 3]; db[200:400, 1] = -0.0
+    ob[400:500, 2] = boxes[2, 4]; db[400:500, 2] = 0.0
+    bt2 = np.array([ref.bbox_intersect(boxes[o], ob, db, best) for o in range(4)])
+    bo2 = np.array([orc.bbox_intersect(boxes[o], ob, db, best) for o in range(4)])
+    check("bbox slab test, NaN paths", bt2, bo2)
+    prim_desc = dict(tris=np.array(tris))
+    np.savez_compressed(os.path.join(GOLD, "prims.npz"), org=org, dir=d, t=t_all, boxes=boxes, best=best, slab=bt, org_nan=ob[:500],
+                        dir_nan=db[:500], slab_nan=bt2[:, :500], **prim_desc)
+
+    # ---------------------------------------------------------------- G5: normals, colours, textures
+    ref = Reference(); orc = Oracle()
+    tex = os.path.join(DATA, "tex.bmp")
+    rm = ref.texture_read(tex); om = orc.texture_read(tex)
+    check("texture resolution", ref.texture_res(rm), orc.texture_res(om))
+    uv = np.r_[rng.uniform(-2.5, 3.5, (4000, 2)), np.array([[0, 0], [1, 1], [1, 0], [0, 1], [2, 2], [-1, -1], [0.5, 1.0], [1e-9, -1e-9]])]
+    rt = ref.texture_get(rm, uv); ot = orc.texture_get(om, uv)
+    check("texture bilinear lookup", rt, ot)
+    np.savez_compressed(os.path.join(GOLD, "texture.npz"), uv=uv, rgb=rt, res=np.array(ref.texture_res(rm)))
+    for api, mp in ((ref, rm), (orc, om)):
+        r2 = np.random.default_rng(11)
+        for i in range(40):
+            A, C, B = r2.uniform(-1, 1, (3, 3))
+            api.add_triangle(A, C, B, (0.2, 0.4, 0.6, 0.0), 1.3)
+            nn = r2.normal(size=(3, 3))
+            if i % 3 != 2:
+                nn /= np.linalg.norm(nn, axis=1)[:, None]
+            api.last_set_normals(nn[0], nn[1], nn[2])
+            tt = r2.uniform(-1, 2, (3, 2))
+            api.last_set_texture(tt[0], tt[1], tt[2], i % 2 == 0, mp)
+        # cascade special cases: AB_y*AC_x - AC_y*AB_x == 0, AB_x == 0, ...
+        for (A, C, B) in [((0, 0, 0), (0, 0, 1), (0, 1, 0)), ((0, 0, 0), (0, 1, 0), (0, 0, 1)), ((1, 1, 1), (1, 1, 2), (2, 1, 1)),
+                          ((0, 0, 0), (1, 0, 0), (0, 0, 1)), ((0, 0, 0), (0, 1, 1), (0, 1, 0))]:
+            api.add_triangle(A, C, B, (0.2, 0.4, 0.6, 0.0), 1.3)
+            api.last_set_normals((0, 0, 1), (0, 1, 0), (1, 0, 0))
+            api.last_set_texture((0, 0), (1, 0), (0, 1), True, mp)
+        for i in range(4):
+            api.add_sphere(r2.uniform(-0.5, 0.5, 3), 0.3, (1, 1, 1, 1.8), 1.5)
+        api.add_triangle((0, 0, 0), (1, 0, 0), (0, 1, 0), (0.9, 0.8, 0.7, 0.0), 1.0)   # flat
+    nprim = ref.size()
+    n = 3000
+    objs = rng.integers(0, nprim, n).astype(np.int32)
+    pos = rng.uniform(-1, 1, (n, 3))
+    with np.errstate(all="ignore"):
+        rn = ref.obj_normal(objs, pos); on = orc.obj_normal(objs, pos)
+        check("normals (smooth/flat/sphere, degenerate cascades)", rn, on)
+        rtg = ref.obj_tangent(objs, pos); otg = orc.obj_tangent(objs, pos)
+        check("tangents", rtg, otg)
+        rc = ref.obj_color(objs, pos); oc = orc.obj_color(objs, pos)
+        check("colours (textured/plain)", rc, oc)
+    nrm = rng.normal(size=(n, 3)); nrm /= np.linalg.norm(nrm, axis=1)[:, None]
+    din = rng.normal(size=(n, 3)); din /= np.linalg.norm(din, axis=1)[:, None]
+    rr = ref.reflect_dir(nrm, din); orr = orc.reflect_dir(nrm, din)
+    check("reflection direction", rr, orr)
+    np.savez_compressed(os.path.join(GOLD, "shading_prims.npz"), objs=objs, pos=pos, normals=rn, tangents=rtg, colors=rc, nrm=nrm, din=din,
+                        refl=rr)
+
+    # ---------------------------------------------------------------- G6: photons, kd-tree, k-NN, radiance estimate
+    for tag, mesh, rgbs, ior, off, nemit in [("cornell", None, None, None, None, 2000), ("water", "water.obj", (0.26, 0.84, 1.0, 1.8), 1.33, (0, 0, 0), 600),
+                                              ("teapot_mirror", "teapot_normal.obj", (1.0, 1.0, 1.0, 0.9), 1.5, (0, -0.7, 0), 600)]:
+        ref = Reference(); orc = Oracle()
+        if mesh:
+            build_scene(ref, mesh, rgbs, ior, off); build_scene(orc, mesh, rgbs, ior, off)
+        else:
+            build_scene(ref, None); build_scene(orc, None)
+        ref.seed(12345); orc.seed(12345)
+        nr = ref.emit_photons(nemit); no = orc.emit_photons(nemit)
+        check(f"photon count {tag} ({nr})", nr, no)
+        rp = ref.photons_get(); op = orc.photons_get()
+        check(f"photon records {tag}", rp[:, :9], op[:, :9])
+        ref.build_kdtree(); orc.build_kdtree()
+        rp = ref.photons_get(); op = orc.photons_get()
+        check(f"photon order after kd build {tag}", rp[:, :9], op[:, :9])
+        check(f"kd topology {tag}", ref.kd_dump(), orc.kd_dump())
+        if tag != "cornell":
+            continue
+        nq = 256
+        centers = np.r_[rp[rng.integers(0, len(rp), nq // 2), :3] + rng.normal(scale=0.02, size=(nq // 2, 3)), rng.uniform(-1, 1, (nq // 2, 3))]
+        gold = dict(photons=rp[:, :9], centers=centers, kd=ref.kd_dump())
+        for k in (8, 50, 1000):
+            ri, rc_, rd = ref.knn(k, centers); oi, oc_, od = orc.knn(k, centers)
+            check(f"knn k={k} counts", rc_, oc_)
+            check(f"knn k={k} distances", rd, od)
+            check(f"knn k={k} indices", ri, oi)
+            gold[f"cnt{k}"] = rc_; gold[f"d2_{k}"] = rd; gold[f"idx{k}"] = ri
+        # getColorAt on diffuse hits (PHOTONMUM=50000, k=1000 compiled into the reference)
+        org, d = ref.primary_rays(48, 48, CAM)
+        ids, t = ref.shoot(org, d)
+        hit = ids >= 0
+        pos = org[hit] + d[hit] * t[hit][:, None]
+        rcol = ref.get_color_at(pos, d[hit], ids[hit], 1); ocol = orc.get_color_at(pos, d[hit], ids[hit], 1)
+        check("getColorAt diffuse (radiance estimate)", rcol, ocol)
+        gold.update(shade_pos=pos, shade_dir=d[hit], shade_obj=ids[hit], shade_rgb=rcol)
+        np.savez_compressed(os.path.join(GOLD, "photons_cornell.npz"), **gold)
+
+    # ---------------------------------------------------------------- G7: small renders per material class (HEAD semantics)
+    with tempfile.TemporaryDirectory() as td:
+        for tag, rgbs, ior in [("diffuse", (0.5, 0.5, 0.5, 0.0), 1.0), ("mirror", (1.0, 1.0, 1.0, 0.9), 1.5), ("glass", (1.0, 1.0, 1.0, 1.8), 1.5)]:
+            ref = Reference(); orc = Oracle()
+            build_scene(ref, "teapot_normal.obj", rgbs, ior, (0, -0.7, 0)); build_scene(orc, "teapot_normal.obj", rgbs, ior, (0, -0.7, 0))
+            ref.seed(12345); orc.seed(12345)
+            ref.emit_photons(3000); orc.emit_photons(3000)
+            ref.build_kdtree(); orc.build_kdtree()
+            w = h = 64
+            org, d = ref.primary_rays(w, h, CAM)
+            ids, t = ref.shoot(org, d)
+            rgb = np.zeros((w * h, 3))
+            hit = (ids >= 0) & (t > 1e-6)
+            pos = org[hit] + d[hit] * t[hit][:, None]
+            rgb[hit] = ref.get_color_at(pos, d[hit], ids[hit], 1)
+            orc.params.head_quirk = 1
+            orgb, nrays = orc.render(w, h, CAM, threads=4)
+            check(f"render 64x64 {tag} (HEAD recursion semantics)", rgb.reshape(h, w, 3), orgb)
+            pr = os.path.join(td, "r.bmp"); po = os.path.join(td, "o.bmp")
+            ref.save_bmp(pr, w, h, rgb); orc.save_bmp(po, w, h, orgb)
+            check(f"bmp bytes {tag}", np.fromfile(pr, np.uint8), np.fromfile(po, np.uint8))
+            np.savez_compressed(os.path.join(GOLD, f"render_{tag}_64.npz"), rgb=rgb.reshape(h, w, 3), bmp=np.fromfile(pr, np.uint8),
+                                photons=ref.photons_get()[:, :9], rgbs=np.array(rgbs), ior=ior)
+
+    print()
+    if failures:
+        print("FAILED:", failures)
+        sys.exit(1)
+    print("all restatement checks passed; goldens written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()
