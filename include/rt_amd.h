@@ -1,0 +1,185 @@
+/* rt_amd.h -- C ABI of the MI355X (gfx950) ray-trace hot path.
+ *
+ * The reference renderer (rossig7/RayTracer) has no FFI: its boundary is the C++ object API that
+ * main.cpp is written against.  This header is the thin C layer the host-side C++ classes of
+ * this project (raytracer_amd/scene/ -- same class and method names as the reference) call to reach
+ * the HIP kernels; each entry point names the reference interface it replaces (file:line relative
+ * to the reference tree).
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or a negative rt_status; rt_last_error() gives the text of
+ *     the last failure on the calling thread.  No exception crosses this boundary.
+ *   - plain pointers and sizes only.  Host pointers unless the parameter name starts with `d_`
+ *     (device memory of the context's GPU).
+ *   - one rt_context per GPU, driven by one host thread at a time; distinct contexts are
+ *     independent.  A context never falls back to the CPU: every entry point that computes fails
+ *     with RT_ERR_NO_DEVICE if no gfx950 device is usable.
+ *   - object ids are indices in insertion order (the reference's scene_objects order, main.cpp:46);
+ *     a miss is id -1 (the reference returns nullptr, BVH.cpp:115,122).
+ */
+#ifndef RT_AMD_H
+#define RT_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1,      /* bad argument (null pointer, size mismatch, unknown enum)      */
+    RT_ERR_NO_DEVICE = -2,    /* no usable gfx950 device / HIP runtime error at context creation */
+    RT_ERR_HIP = -3,          /* a HIP call or kernel launch failed                              */
+    RT_ERR_STATE = -4,        /* call order violated (e.g. trace before scene upload)            */
+    RT_ERR_IO = -5,           /* file could not be read / written                                */
+    RT_ERR_LIMIT = -6         /* a compiled-in limit was exceeded (e.g. BVH deeper than the traversal stack) */
+} rt_status;
+
+/* arithmetic the kernels run in.  RT_F64 reproduces the reference bit for bit (hit ids, t);
+ * RT_F32 is the FP32-VALU throughput instantiation of the same kernel source. */
+typedef enum rt_precision { RT_F64 = 0, RT_F32 = 1 } rt_precision;
+
+typedef struct rt_context rt_context;
+typedef struct rt_scene rt_scene;
+
+/* Camera exactly as main.cpp:626-635 builds it (all double): position, direction, right, down. */
+typedef struct rt_camera {
+    double pos[3];
+    double dir[3];
+    double right[3];
+    double down[3];
+} rt_camera;
+
+/* Run-time form of the reference's compile-time constants (main.cpp:21-39, Kdtree.cpp:6) and of
+ * the locals of main() (main.cpp:605-614).  rt_default_params() fills the reference's values. */
+typedef struct rt_render_params {
+    uint32_t struct_size;     /* sizeof(rt_render_params), checked                               */
+    int32_t width, height;    /* main.cpp:606-607                                                */
+    int32_t aadepth;          /* main.cpp:610; aadepth^2 samples, reference sample pattern       */
+    int32_t tracing_depth;    /* TRACING_DEPTH, main.cpp:28                                      */
+    int32_t photon_num;       /* PHOTONMUM, main.cpp:21 (normalisation of the radiance estimate) */
+    int32_t photon_use;       /* PHOTONUSE, main.cpp:22 (k of the k-NN gather)                   */
+    int32_t head_quirk;       /* 1: recurse with the *old* hit object as HEAD does (main.cpp:198,249) */
+    int32_t use_photon_map;   /* 0: diffuse hits shade black (no gather)                         */
+    int32_t precision;        /* rt_precision of traversal + shading                             */
+    int32_t shadow_rays;      /* extension (not in the reference): one occlusion ray per diffuse primary hit toward light_pos */
+    double accuracy;          /* main.cpp:614                                                    */
+    double photon_dist;       /* PHOTONDIST, Kdtree.cpp:6                                        */
+    double light_pos[3];      /* main.cpp:654                                                    */
+} rt_render_params;
+
+/* Ray counters of one call (the Mrays/s metric counts closest-hit queries, i.e. BVH::Shoot calls). */
+typedef struct rt_stats {
+    uint64_t primary_rays;
+    uint64_t secondary_rays;  /* reflection + refraction */
+    uint64_t shadow_rays;
+    uint64_t gather_queries;  /* KDTree::findKNN calls */
+    double kernel_ms;         /* device time of the call measured with HIP events on the context's stream */
+    double trace_kernel_ms;   /* device time of the traversal kernel launches only */
+} rt_stats;
+
+/* ---- process / context ------------------------------------------------------------------- */
+int rt_abi_version(void);
+const char* rt_last_error(void);
+int rt_device_count(void);
+int rt_context_create(int device, rt_context** out);
+void rt_context_destroy(rt_context* ctx);
+/* the HIP stream (hipStream_t) all work of this context is enqueued on */
+void* rt_context_stream(rt_context* ctx);
+int rt_context_synchronize(rt_context* ctx);
+void rt_default_params(rt_render_params* p);
+/* camera basis from position + look-at, main.cpp:626-635 */
+void rt_camera_look_at(const double pos[3], const double look_at[3], rt_camera* out);
+
+/* ---- host scene assembly: replaces `vector<Object*> scene_objects` + `new BVH(scene_objects)`
+ *      (main.cpp:46,660-678).  Argument orders are the reference constructors'. ------------------ */
+int rt_scene_create(rt_scene** out);
+void rt_scene_destroy(rt_scene* s);
+int rt_scene_size(const rt_scene* s);
+/* Triangle(A, C, B, color, ior), Triangle.h:137; returns the object id or <0 */
+int rt_scene_add_triangle(rt_scene* s, const double A[3], const double C[3], const double B[3], const double rgbs[4], float ior);
+/* Triangle::setNormals(a, c, b), Triangle.h:150 */
+int rt_scene_set_normals(rt_scene* s, int obj, const double na[3], const double nc[3], const double nb[3]);
+/* Triangle::setTexture(tA, tC, tB, use, map), Triangle.h:106 */
+int rt_scene_set_texture(rt_scene* s, int obj, const double ta[2], const double tc[2], const double tb[2], int use_texture, int map);
+/* Sphere(center, radius, color, ior), Sphere.h:100 */
+int rt_scene_add_sphere(rt_scene* s, const double center[3], double radius, const double rgbs[4], float ior);
+/* Plane(normal, distance, color), Plane.h:48.  Planes have no bounding box: they are kept in a
+ * side list tested after the BVH with the same accept rule (the reference cannot instantiate Plane). */
+int rt_scene_add_plane(rt_scene* s, const double normal[3], double distance, const double rgbs[4]);
+/* makeCornellBox / makeCube, IO.cpp:108 / IO.cpp:70 */
+int rt_scene_add_cornell_box(rt_scene* s, const double corner1[3], const double corner2[3]);
+int rt_scene_add_cube(rt_scene* s, const double corner1[3], const double corner2[3], const double rgbs[4]);
+/* ObjReader(file, color, ior, xoff, yoff, zoff, map, use_texture)::ReadContent, IO.h:34,61.
+ * Tolerates faces without vt / vn indices (the reference crashes on them, IO.h:91-101). */
+int rt_scene_load_obj(rt_scene* s, const char* path, const double rgbs[4], float ior, float xoff, float yoff, float zoff,
+                      int use_texture, int map);
+/* TextureMap::TextureMapRead, TextureMap.h:20; returns the map index or <0 */
+int rt_scene_add_texture_bmp(rt_scene* s, const char* path);
+/* rows x cols texels, rgb doubles in [0,1], row-major as TextureMap::ColorMap[x][y] */
+int rt_scene_add_texture_rgb(rt_scene* s, int x_res, int y_res, const double* rgb);
+/* BVH::BVH(vector<Object*>&), BVH.cpp:98: same topology, leaf order and boxes as the reference */
+int rt_scene_build_bvh(rt_scene* s);
+/* topology in pre-order for tests: rec = per node [is_leaf, n, ids...], boxes = 6 doubles per node.
+ * Call with NULL buffers to get the sizes. */
+int rt_scene_bvh_dump(const rt_scene* s, int32_t* rec, int64_t* n_rec, double* boxes, int64_t* n_boxes);
+int rt_scene_bvh_depth(const rt_scene* s);
+
+/* ---- device: scene + traversal ----------------------------------------------------------- */
+/* copy the flattened scene (64 B-aligned node / primitive / material arrays, f64 and f32 forms) to HBM */
+int rt_scene_upload(rt_context* ctx, const rt_scene* s);
+
+/* BVH::Shoot(ray, dist) for a batch, BVH.cpp:108.  org/dir: n x 3 doubles; dist: in = max range
+ * (the reference's in/out `distance`), out = hit distance (unchanged on a miss); ids: object id or -1.
+ * Host buffers (copied through PCIe, not the measured path). */
+int rt_trace_closest(rt_context* ctx, int precision, int64_t n, const double* org, const double* dir, double* dist, int32_t* ids);
+/* same with device-resident SoA rays: d_org/d_dir point to 3*n doubles laid out x[n],y[n],z[n];
+ * d_dist n doubles in/out, d_ids n int32.  Enqueued on the context stream, not synchronised. */
+int rt_trace_closest_dev(rt_context* ctx, int precision, int64_t n, const double* d_org, const double* d_dir, double* d_dist, int32_t* d_ids);
+
+/* Primary rays of the pixel loop generated on the device (main.cpp:753-790, aadepth 1) + BVH::Shoot
+ * (main.cpp:812-813) for image rows [row_begin,row_end); optionally one shadow (occlusion) ray per
+ * hit toward light_pos.  d_ids / d_t / d_shadow_ids are device arrays indexed by
+ * (y-row_begin)*width+x; d_t and d_shadow_ids may be NULL.  Enqueued, not synchronised. */
+int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end,
+                         int32_t* d_ids, double* d_t, int32_t* d_shadow_ids, rt_stats* stats);
+/* host-buffer convenience form of the above (synchronises) */
+int rt_trace_primary(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end,
+                     int32_t* ids, double* t, int32_t* shadow_ids, rt_stats* stats);
+
+/* ---- device: photon map -------------------------------------------------------------------- */
+/* KDTree(vector<Photon*>&), Kdtree.h:59 + Kdtree.cpp:11-61: builds the reference's kd-tree on the
+ * host (same topology), flattens it and copies it to HBM.  photons: n x 9 doubles
+ * (position, power rgb, direction; Photon.h:7-28).  which: 0 surface map, 1 volume map. */
+int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photons);
+/* KDTree::findKNN(k, center), Kdtree.cpp:135, for a batch: counts[n], and (optional) the squared
+ * distance of the farthest returned photon r2[n] (-1 when none). */
+int rt_knn_radius(rt_context* ctx, int which, int k, double max_dist, int64_t n, const double* centers, int32_t* counts, double* r2);
+/* findKNN + the radiance estimate of main.cpp:260-295 for a batch of diffuse hits:
+ * pos/normal n x 3, color n x 3 (hit colour), rgb out n x 3 (clipped as Color::clip) */
+int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal,
+                    const double* color, double* rgb, int32_t* counts);
+
+/* ---- device: full pixel path ------------------------------------------------------------- */
+/* The pixel loop of main.cpp:735-861 for rows [row_begin,row_end): primary rays, BVH::Shoot,
+ * getColorAt (main.cpp:158-392: reflection / refraction bounce queue + photon gather) and the
+ * quantiser of saveBmp (IO.cpp:55-65).  d_rgb: (rows*width*3) doubles (may be NULL);
+ * d_bgr8: (rows*width*3) bytes B,G,R (may be NULL).  Enqueued, not synchronised. */
+int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end,
+                       double* d_rgb, uint8_t* d_bgr8, rt_stats* stats);
+int rt_render_rows(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end,
+                   double* rgb, uint8_t* bgr8, rt_stats* stats);
+
+/* ---- host I/O either side of the path ---------------------------------------------------- */
+/* saveBmp(filename, w, h, dpi, data), IO.cpp:5: byte-identical file (header quirks included) */
+int rt_save_bmp(const char* path, int w, int h, int dpi, const double* rgb);
+int rt_save_bmp_bgr8(const char* path, int w, int h, int dpi, const uint8_t* bgr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_AMD_H */

@@ -1,0 +1,179 @@
+"""raytracer_amd: MI355X (gfx950) ray-trace hot path behind the reference renderer's scene API.
+
+The product is the C-ABI library librt_amd.so (HIP kernels + host scene code, sources in csrc/)
+and the C++ scene headers in scene/.  This Python package is thin plumbing over that ABI for the
+tests and the benchmark: numpy arrays in, numpy arrays out, torch device pointers passed through.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import RT_F32, RT_F64, Camera, RenderParams, Stats, lib
+
+__all__ = ["Scene", "Context", "RtError", "RT_F32", "RT_F64", "default_params", "look_at", "save_bmp"]
+
+
+class RtError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__(f"{where}: status {code}: {lib.rt_last_error().decode(errors='replace')}")
+
+
+def _chk(code, where):
+    if code < 0:
+        raise RtError(code, where)
+    return code
+
+
+def _dp(a):
+    return a.ctypes.data_as(_lib.P(_lib.c_d))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def default_params(**kw):
+    p = RenderParams()
+    lib.rt_default_params(ctypes.byref(p))
+    for k, v in kw.items():
+        if k == "light_pos":
+            for i in range(3):
+                p.light_pos[i] = v[i]
+        else:
+            setattr(p, k, v)
+    return p
+
+
+def look_at(pos=(2.8, 0, 0), target=(0, 0, 0)):
+    cam = Camera()
+    lib.rt_camera_look_at(_dp(_f64(pos)), _dp(_f64(target)), ctypes.byref(cam))
+    return cam
+
+
+class Scene:
+    """Host scene assembly (mirrors `vector<Object*> scene_objects` + `new BVH(scene_objects)`)."""
+
+    def __init__(self):
+        h = ctypes.c_void_p()
+        _chk(lib.rt_scene_create(ctypes.byref(h)), "rt_scene_create")
+        self.h = h
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.rt_scene_destroy(self.h)
+            self.h = None
+
+    def size(self):
+        return lib.rt_scene_size(self.h)
+
+    def add_triangle(self, A, C, B, rgbs, ior=1.0):
+        return _chk(lib.rt_scene_add_triangle(self.h, _dp(_f64(A)), _dp(_f64(C)), _dp(_f64(B)), _dp(_f64(rgbs)), ior), "rt_scene_add_triangle")
+
+    def set_normals(self, obj, na, nc, nb):
+        _chk(lib.rt_scene_set_normals(self.h, obj, _dp(_f64(na)), _dp(_f64(nc)), _dp(_f64(nb))), "rt_scene_set_normals")
+
+    def set_texture(self, obj, ta, tc, tb, use, map_idx):
+        _chk(lib.rt_scene_set_texture(self.h, obj, _dp(_f64(ta)), _dp(_f64(tc)), _dp(_f64(tb)), int(use), map_idx), "rt_scene_set_texture")
+
+    def add_sphere(self, c, radius, rgbs, ior=1.0):
+        return _chk(lib.rt_scene_add_sphere(self.h, _dp(_f64(c)), radius, _dp(_f64(rgbs)), ior), "rt_scene_add_sphere")
+
+    def add_plane(self, normal, distance, rgbs):
+        return _chk(lib.rt_scene_add_plane(self.h, _dp(_f64(normal)), distance, _dp(_f64(rgbs))), "rt_scene_add_plane")
+
+    def add_cornell(self, c1=(1, 1, 1), c2=(-1, -1, -1)):
+        _chk(lib.rt_scene_add_cornell_box(self.h, _dp(_f64(c1)), _dp(_f64(c2))), "rt_scene_add_cornell_box")
+
+    def add_cube(self, c1, c2, rgbs):
+        _chk(lib.rt_scene_add_cube(self.h, _dp(_f64(c1)), _dp(_f64(c2)), _dp(_f64(rgbs))), "rt_scene_add_cube")
+
+    def load_obj(self, path, rgbs=(0.5, 0.5, 0.5, 0.0), ior=1.0, off=(0, 0, 0), use_texture=False, map_idx=-1):
+        _chk(lib.rt_scene_load_obj(self.h, path.encode(), _dp(_f64(rgbs)), ior, off[0], off[1], off[2], int(use_texture), map_idx),
+             "rt_scene_load_obj")
+        return 1
+
+    def add_texture_bmp(self, path):
+        return _chk(lib.rt_scene_add_texture_bmp(self.h, path.encode()), "rt_scene_add_texture_bmp")
+
+    def add_texture_rgb(self, rgb):
+        rgb = _f64(rgb)
+        return _chk(lib.rt_scene_add_texture_rgb(self.h, rgb.shape[0], rgb.shape[1], _dp(rgb)), "rt_scene_add_texture_rgb")
+
+    def build_bvh(self):
+        _chk(lib.rt_scene_build_bvh(self.h), "rt_scene_build_bvh")
+
+    def bvh_depth(self):
+        return lib.rt_scene_bvh_depth(self.h)
+
+    def bvh_dump(self):
+        n_rec = ctypes.c_int64(0)
+        n_box = ctypes.c_int64(0)
+        _chk(lib.rt_scene_bvh_dump(self.h, None, ctypes.byref(n_rec), None, ctypes.byref(n_box)), "rt_scene_bvh_dump")
+        rec = np.zeros(n_rec.value, np.int32)
+        boxes = np.zeros((n_box.value, 6))
+        _chk(lib.rt_scene_bvh_dump(self.h, rec.ctypes.data_as(_lib.P(_lib.c_i32)), ctypes.byref(n_rec), _dp(boxes), ctypes.byref(n_box)),
+             "rt_scene_bvh_dump")
+        return rec, boxes
+
+
+class Context:
+    """One GPU.  Raises RtError (RT_ERR_NO_DEVICE) when no gfx950 device is usable -- never falls back."""
+
+    def __init__(self, device=0):
+        h = ctypes.c_void_p()
+        _chk(lib.rt_context_create(device, ctypes.byref(h)), "rt_context_create")
+        self.h = h
+        self.device = device
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.rt_context_destroy(self.h)
+            self.h = None
+
+    @property
+    def stream(self):
+        return lib.rt_context_stream(self.h)
+
+    def synchronize(self):
+        _chk(lib.rt_context_synchronize(self.h), "rt_context_synchronize")
+
+    def upload(self, scene):
+        _chk(lib.rt_scene_upload(self.h, scene.h), "rt_scene_upload")
+
+    def trace_closest(self, org, d, max_dist=1e9, precision=RT_F64):
+        org = _f64(org); d = _f64(d)
+        n = org.shape[0]
+        dist = np.full(n, max_dist, dtype=np.float64) if np.isscalar(max_dist) else _f64(max_dist).copy()
+        ids = np.zeros(n, np.int32)
+        _chk(lib.rt_trace_closest(self.h, precision, n, _dp(org), _dp(d), _dp(dist), ids.ctypes.data_as(_lib.P(_lib.c_i32))), "rt_trace_closest")
+        return ids, dist
+
+    def trace_closest_dev(self, n, d_org, d_dir, d_dist, d_ids, precision=RT_F64):
+        """Device pointers (ints): SoA rays.  Enqueued on the context stream."""
+        _chk(lib.rt_trace_closest_dev(self.h, precision, n, d_org, d_dir, d_dist, d_ids), "rt_trace_closest_dev")
+
+    def trace_primary(self, cam, params, rows=None, want_t=True):
+        r0, r1 = rows if rows else (0, params.height)
+        n = params.width * (r1 - r0)
+        ids = np.zeros(n, np.int32)
+        t = np.zeros(n) if want_t else None
+        sh = np.zeros(n, np.int32) if params.shadow_rays else None
+        st = Stats()
+        _chk(lib.rt_trace_primary(self.h, ctypes.byref(cam), ctypes.byref(params), r0, r1, ids.ctypes.data_as(_lib.P(_lib.c_i32)),
+                                  _dp(t) if want_t else None, sh.ctypes.data_as(_lib.P(_lib.c_i32)) if sh is not None else None,
+                                  ctypes.byref(st)), "rt_trace_primary")
+        return ids, t, sh, st
+
+    def trace_primary_dev(self, cam, params, rows, d_ids, d_t=None, d_shadow=None, stats=True):
+        st = Stats()
+        _chk(lib.rt_trace_primary_dev(self.h, ctypes.byref(cam), ctypes.byref(params), rows[0], rows[1], d_ids, d_t, d_shadow,
+                                      ctypes.byref(st) if stats else None), "rt_trace_primary_dev")
+        return st
+
+
+def save_bmp(path, rgb, dpi=72):
+    rgb = _f64(rgb)
+    h, w = rgb.shape[0], rgb.shape[1]
+    _chk(lib.rt_save_bmp(path.encode(), w, h, dpi, _dp(rgb)), "rt_save_bmp")

@@ -1,0 +1,460 @@
+// Host scene assembly + BVH build/flatten.  See host_scene.h.
+#include "host_scene.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <array>
+
+#include "rt_math.h"
+
+namespace rth {
+
+static void cp3(double* d, const double* s) { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
+
+// ---------------------------------------------------------------- scene assembly
+int Scene::add_triangle(const double* A, const double* C, const double* B, const double* rgbs, float ior)
+{
+    // Triangle(pointA, pointC, pointB, ...) stores A = 1st, C = 2nd, B = 3rd argument (Triangle.h:137-140)
+    Object o{};
+    o.sh.kind = rtf::PRIM_TRI;
+    cp3(o.sh.A, A); cp3(o.sh.B, B); cp3(o.sh.C, C);
+    rtm::D3 n = rtm::tri_normal(o.sh);          // NormalA/B/C start as the face normal (Triangle.h:141-143)
+    double nn[3] = {n.x, n.y, n.z};
+    cp3(o.sh.NA, nn); cp3(o.sh.NB, nn); cp3(o.sh.NC, nn);
+    for (int i = 0; i < 4; i++) o.sh.color[i] = rgbs[i];
+    o.sh.ior = ior;
+    o.sh.map = -1;
+    objects.push_back(o);
+    bvh.built = false;
+    return (int)objects.size() - 1;
+}
+
+int Scene::set_normals(int obj, const double* na, const double* nc, const double* nb)
+{
+    if (obj < 0 || obj >= (int)objects.size() || objects[obj].sh.kind != rtf::PRIM_TRI) return -1;
+    rtf::ObjShade& s = objects[obj].sh;       // setNormals(a, c, b), Triangle.h:150-156
+    cp3(s.NA, na); cp3(s.NB, nb); cp3(s.NC, nc);
+    s.has_normal = 1;
+    return 0;
+}
+
+int Scene::set_texture(int obj, const double* ta, const double* tc, const double* tb, int use, int map)
+{
+    if (obj < 0 || obj >= (int)objects.size() || objects[obj].sh.kind != rtf::PRIM_TRI) return -1;
+    if (use && (map < 0 || map >= (int)textures.size())) return -1;
+    rtf::ObjShade& s = objects[obj].sh;       // setTexture(A, C, B, use, map), Triangle.h:106-113
+    s.tA[0] = ta[0]; s.tA[1] = ta[1]; s.tB[0] = tb[0]; s.tB[1] = tb[1]; s.tC[0] = tc[0]; s.tC[1] = tc[1];
+    s.has_texture = use ? 1 : 0;
+    s.map = map;
+    return 0;
+}
+
+int Scene::add_sphere(const double* c, double radius, const double* rgbs, float ior)
+{
+    Object o{};
+    o.sh.kind = rtf::PRIM_SPHERE;
+    cp3(o.sh.A, c);
+    o.sh.B[0] = radius;
+    for (int i = 0; i < 4; i++) o.sh.color[i] = rgbs[i];
+    o.sh.ior = ior;
+    o.sh.map = -1;
+    objects.push_back(o);
+    bvh.built = false;
+    return (int)objects.size() - 1;
+}
+
+int Scene::add_plane(const double* n, double distance, const double* rgbs)
+{
+    Object o{};
+    o.sh.kind = rtf::PRIM_PLANE;
+    cp3(o.sh.A, n);
+    o.sh.B[0] = distance;
+    for (int i = 0; i < 4; i++) o.sh.color[i] = rgbs[i];
+    o.sh.ior = 1;                             // Object::getRefraIdx default, Object.h:28
+    o.sh.map = -1;
+    objects.push_back(o);
+    bvh.built = false;
+    return (int)objects.size() - 1;
+}
+
+namespace {
+struct Corners { double A[3], B[3], C[3], D[3], E[3], F[3]; };
+// the six derived corners of IO.cpp:80-86 / :118-124
+Corners corners(const double* c1, const double* c2)
+{
+    Corners k;
+    double a[3] = {c2[0], c1[1], c1[2]}, b[3] = {c2[0], c1[1], c2[2]}, c[3] = {c1[0], c1[1], c2[2]};
+    double d[3] = {c2[0], c2[1], c1[2]}, e[3] = {c1[0], c2[1], c1[2]}, f[3] = {c1[0], c2[1], c2[2]};
+    cp3(k.A, a); cp3(k.B, b); cp3(k.C, c); cp3(k.D, d); cp3(k.E, e); cp3(k.F, f);
+    return k;
+}
+}  // namespace
+
+void Scene::add_cornell_box(const double* c1, const double* c2)
+{
+    // IO.cpp:108-154: left (green), far (white), right (red), top, bottom; the camera side stays open
+    Corners k = corners(c1, c2);
+    const double red[4] = {1, 0.25, 0.25, 0}, green[4] = {0.25, 1, 0.25, 0}, white[4] = {1.0, 1.0, 1.0, 0};
+    const double* tri[10][4] = {
+        {k.D, k.A, c1, green}, {c1, k.E, k.D, green}, {c2, k.B, k.A, white}, {k.A, k.D, c2, white}, {k.F, k.C, k.B, red},
+        {k.B, c2, k.F, red},   {k.D, k.E, k.F, white}, {k.F, c2, k.D, white}, {c1, k.A, k.B, white}, {k.B, k.C, c1, white}};
+    for (auto& t : tri) add_triangle(t[0], t[1], t[2], t[3], 20);
+}
+
+void Scene::add_cube(const double* c1, const double* c2, const double* rgbs)
+{
+    // IO.cpp:70-106: left, far, right, front, top, bottom
+    Corners k = corners(c1, c2);
+    const double* tri[12][3] = {{k.D, k.A, c1}, {c1, k.E, k.D}, {c2, k.B, k.A}, {k.A, k.D, c2}, {k.F, k.C, k.B}, {k.B, c2, k.F},
+                                {k.E, c1, k.C}, {k.C, k.F, k.E}, {k.D, k.E, k.F}, {k.F, c2, k.D}, {c1, k.A, k.B}, {k.B, k.C, c1}};
+    for (auto& t : tri) add_triangle(t[0], t[1], t[2], rgbs, 2);
+}
+
+// ---------------------------------------------------------------- OBJ loader (IO.h:22-125)
+namespace {
+// one face corner "v", "v/vt", "v//vn" or "v/vt/vn" -> zero-based indices, -1 when absent
+void parse_corner(const std::string& tok, int& v, int& vt, int& vn)
+{
+    v = vt = vn = -1;
+    const char* s = tok.c_str();
+    char* end = nullptr;
+    long a = strtol(s, &end, 10);
+    if (end != s) v = (int)a - 1;
+    if (*end != '/') return;
+    s = end + 1;
+    if (*s != '/') {
+        long b = strtol(s, &end, 10);
+        if (end != s) vt = (int)b - 1;
+    } else {
+        end = const_cast<char*>(s);
+    }
+    if (*end != '/') return;
+    s = end + 1;
+    long c = strtol(s, &end, 10);
+    if (end != s) vn = (int)c - 1;
+}
+}  // namespace
+
+int Scene::load_obj(const char* path, const double* rgbs, float ior, float xo, float yo, float zo, int use_texture, int map)
+{
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return -1;                      // the reference returns false silently (IO.h:72-73)
+    std::string text;
+    char buf[1 << 16];
+    size_t got;
+    while ((got = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, got);
+    fclose(fp);
+
+    // whitespace-separated words, exactly like the reference's `input >> head` stream (IO.h:75-119):
+    // comment text is just a run of unknown words
+    std::vector<std::string> words;
+    {
+        size_t i = 0, n = text.size();
+        while (i < n) {
+            while (i < n && isspace((unsigned char)text[i])) i++;
+            size_t j = i;
+            while (j < n && !isspace((unsigned char)text[j])) j++;
+            if (j > i) words.emplace_back(text, i, j - i);
+            i = j;
+        }
+    }
+    std::vector<std::array<double, 3>> points, normals;
+    std::vector<std::array<double, 2>> uvs;
+    auto num = [&](size_t k) { return k < words.size() ? strtod(words[k].c_str(), nullptr) : 0.0; };
+    for (size_t w = 0; w < words.size(); w++) {
+        const std::string& head = words[w];
+        if (head == "v") {
+            points.push_back({num(w + 1) + xo, num(w + 2) + yo, num(w + 3) + zo});
+            w += 3;
+        } else if (head == "vn") {
+            normals.push_back({num(w + 1), num(w + 2), num(w + 3)});
+            w += 3;
+        } else if (head == "vt") {
+            uvs.push_back({num(w + 1), num(w + 2)});
+            w += 2;
+        } else if (head == "f") {
+            if (w + 3 >= words.size()) break;   // truncated face at end of file
+            int v[3], vt[3], vn[3];
+            for (int k = 0; k < 3; k++) parse_corner(words[w + 1 + k], v[k], vt[k], vn[k]);
+            w += 3;
+            for (int k = 0; k < 3; k++)
+                if (v[k] < 0 || v[k] >= (int)points.size()) return -2;   // reference: vector::at throws
+            // new Triangle(points[v0], points[v1], points[v2], ...) = ctor order (A, C, B), IO.h:103
+            int id = add_triangle(points[v[0]].data(), points[v[1]].data(), points[v[2]].data(), rgbs, ior);
+            bool has_n = true, has_t = true;
+            for (int k = 0; k < 3; k++) {
+                has_n = has_n && vn[k] >= 0 && vn[k] < (int)normals.size();
+                has_t = has_t && vt[k] >= 0 && vt[k] < (int)uvs.size();
+            }
+            if (has_n) set_normals(id, normals[vn[0]].data(), normals[vn[1]].data(), normals[vn[2]].data());   // IO.h:104
+            if (has_t) {                                                                                         // IO.h:105
+                rtf::ObjShade& s = objects[id].sh;
+                s.tA[0] = uvs[vt[0]][0]; s.tA[1] = uvs[vt[0]][1];
+                s.tC[0] = uvs[vt[1]][0]; s.tC[1] = uvs[vt[1]][1];
+                s.tB[0] = uvs[vt[2]][0]; s.tB[1] = uvs[vt[2]][1];
+                s.has_texture = (use_texture && map >= 0 && map < (int)textures.size()) ? 1 : 0;
+                s.map = map;
+            }
+        }
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- textures (TextureMap.h:20-61)
+int Scene::add_texture_bmp(const char* path)
+{
+    FILE* fp = fopen(path, "rb");
+    if (!fp) return -1;
+    unsigned char header[54];
+    if (fread(header, 1, 54, fp) != 54) { fclose(fp); return -1; }
+    Texture t;
+    // width (bytes 18-21) is the inner, column count y_res; height (22-25) the row count x_res
+    t.y_res = header[18] | header[19] << 8 | header[20] << 16 | header[21] << 24;
+    t.x_res = header[22] | header[23] << 8 | header[24] << 16 | header[25] << 24;
+    if (t.x_res <= 0 || t.y_res <= 0) { fclose(fp); return -1; }
+    size_t n = (size_t)t.x_res * t.y_res;
+    std::vector<unsigned char> raw(n * 3, 0);
+    size_t got = fread(raw.data(), 1, raw.size(), fp);   // no row padding is skipped, as in the reference
+    (void)got;
+    fclose(fp);
+    t.rgb.resize(n * 3);
+    for (size_t i = 0; i < n; i++) {
+        t.rgb[3 * i] = raw[3 * i + 2] / 255.0;       // file order is B, G, R (TextureMap.h:50-53)
+        t.rgb[3 * i + 1] = raw[3 * i + 1] / 255.0;
+        t.rgb[3 * i + 2] = raw[3 * i] / 255.0;
+    }
+    textures.push_back(std::move(t));
+    return (int)textures.size() - 1;
+}
+
+int Scene::add_texture_rgb(int x_res, int y_res, const double* rgb)
+{
+    if (x_res <= 0 || y_res <= 0 || !rgb) return -1;
+    Texture t;
+    t.x_res = x_res; t.y_res = y_res;
+    t.rgb.assign(rgb, rgb + (size_t)x_res * y_res * 3);
+    textures.push_back(std::move(t));
+    return (int)textures.size() - 1;
+}
+
+// ---------------------------------------------------------------- BVH build (BVH.cpp:26-106)
+Box object_box(const rtf::ObjShade& o)
+{
+    Box b;
+    if (o.kind == rtf::PRIM_TRI) {            // Triangle::getBBox, Triangle.h:115-125
+        for (int i = 0; i < 3; i++) {
+            b.lo[i] = std::min(o.A[i], std::min(o.B[i], o.C[i]));
+            b.hi[i] = std::max(o.A[i], std::max(o.B[i], o.C[i]));
+        }
+    } else {                                  // Sphere::getBBox, Sphere.h:17-27
+        for (int i = 0; i < 3; i++) { b.lo[i] = o.A[i] - o.B[0]; b.hi[i] = o.A[i] + o.B[0]; }
+    }
+    return b;
+}
+
+namespace {
+
+inline Box unite(const Box& a, const Box& b)   // BBox::Union, BVH.cpp:31-40
+{
+    Box r;
+    for (int i = 0; i < 3; i++) { r.lo[i] = std::min(a.lo[i], b.lo[i]); r.hi[i] = std::max(a.hi[i], b.hi[i]); }
+    return r;
+}
+// BBox::Size, BVH.h:33-38 -- evaluation order kept (it decides which split wins on near-ties)
+inline double extent_sum(const Box& b) { return b.hi[0] - b.lo[0] + b.hi[1] - b.lo[1] + b.hi[2] - b.lo[2]; }
+
+rtf::Prim<double> make_prim(const rtf::ObjShade& o, uint32_t id)
+{
+    rtf::Prim<double> p{};
+    p.id = id;
+    p.kind = o.kind;
+    if (o.kind == rtf::PRIM_TRI) {
+        for (int i = 0; i < 3; i++) { p.a[i] = o.A[i]; p.e1[i] = o.B[i] - o.A[i]; p.e2[i] = o.C[i] - o.A[i]; }
+    } else {
+        for (int i = 0; i < 3; i++) p.a[i] = o.A[i];
+        p.e1[0] = o.B[0];
+    }
+    return p;
+}
+
+struct Builder {
+    const std::vector<Object>& objs;
+    std::vector<Box> box;                        // per object
+    std::vector<std::array<double, 3>> centre;   // BBox::Center, BVH.h:23-28
+    FlatBVH& out;
+
+    // returns the child reference and its box for a node holding `ids` (in the node's object order)
+    uint32_t build(std::vector<int>& ids, Box& node_box, int level)
+    {
+        if (level > out.depth) out.depth = level;
+        if (ids.size() < 16) {                   // leaf: BVH.h:45, BVH.cpp:59
+            node_box = box[ids[0]];              // calculateBBox, BVH.cpp:44-49
+            for (int id : ids) node_box = unite(node_box, box[id]);
+            uint32_t first = (uint32_t)out.prims.size();
+            for (int id : ids) out.prims.push_back(make_prim(objs[id].sh, (uint32_t)id));
+            out.n_leaves++;
+            return rtf::make_leaf(first, (uint32_t)ids.size());
+        }
+        size_t n = ids.size();
+        // axis with the widest spread of box centres, first maximum wins (BVH.cpp:61-67)
+        double span[3];
+        for (int ax = 0; ax < 3; ax++) {
+            double mn = centre[ids[0]][ax], mx = mn;
+            for (int id : ids) { mn = std::min(mn, centre[id][ax]); mx = std::max(mx, centre[id][ax]); }
+            span[ax] = mx - mn;
+        }
+        int axis = int(std::max_element(span, span + 3) - span);
+        // the same std::sort call on the same initial order with an equivalent comparator gives the
+        // reference's permutation, ties included (BVH.cpp:68)
+        std::sort(ids.begin(), ids.end(), [&](int a, int b) { return centre[a][axis] < centre[b][axis]; });
+        // prefix / suffix boxes and the sum-of-extents cost over the middle third (BVH.cpp:69-85)
+        std::vector<Box> left(n), right(n);
+        left[0] = box[ids[0]];
+        right[0] = box[ids[n - 1]];
+        for (size_t i = 1; i < n; i++) {
+            left[i] = unite(left[i - 1], box[ids[i]]);
+            right[i] = unite(right[i - 1], box[ids[n - 1 - i]]);
+        }
+        int bad_zone = std::max(1, (int)n / 3);
+        size_t split_pos = 0;
+        double best = 1e9;                      // entries outside the zone keep 1e9; first minimum wins
+        for (size_t i = 0; i < n; i++) {
+            double q = 1e9;
+            if (!((int)i < bad_zone || i > n - 1 - bad_zone)) q = extent_sum(left[i]) + extent_sum(right[n - 1 - i]);
+            if (q < best) { best = q; split_pos = i; }
+        }
+        std::vector<Box>().swap(left);
+        std::vector<Box>().swap(right);
+        std::vector<int> l(ids.begin(), ids.begin() + split_pos + 1), r(ids.begin() + split_pos + 1, ids.end());
+        std::vector<int>().swap(ids);
+        uint32_t me = (uint32_t)out.nodes.size();
+        out.nodes.emplace_back();
+        Box b0, b1;
+        uint32_t c0 = build(l, b0, level + 1);
+        uint32_t c1 = build(r, b1, level + 1);
+        rtf::Node<double>& nd = out.nodes[me];
+        for (int i = 0; i < 3; i++) { nd.lo0[i] = b0.lo[i]; nd.hi0[i] = b0.hi[i]; nd.lo1[i] = b1.lo[i]; nd.hi1[i] = b1.hi[i]; }
+        nd.c0 = c0;
+        nd.c1 = c1;
+        node_box = unite(b0, b1);               // calculateBBox for an inner node, BVH.cpp:52-53
+        return me;
+    }
+};
+
+}  // namespace
+
+void Scene::build_bvh()
+{
+    bvh = FlatBVH{};
+    std::vector<int> ids;
+    Builder b{objects, {}, {}, bvh};
+    b.box.resize(objects.size());
+    b.centre.resize(objects.size());
+    for (size_t i = 0; i < objects.size(); i++) {
+        const rtf::ObjShade& o = objects[i].sh;
+        if (o.kind == rtf::PRIM_PLANE) {
+            bvh.planes.push_back(make_prim(o, (uint32_t)i));
+            continue;
+        }
+        b.box[i] = object_box(o);
+        for (int ax = 0; ax < 3; ax++) b.centre[i][ax] = (b.box[i].hi[ax] + b.box[i].lo[ax]) / 2;
+        ids.push_back((int)i);
+    }
+    if (!ids.empty()) bvh.root_ref = b.build(ids, bvh.root_box, 0);
+    bvh.built = true;
+}
+
+void Scene::bvh_dump(std::vector<int32_t>& rec, std::vector<double>& boxes) const
+{
+    rec.clear();
+    boxes.clear();
+    if (bvh.root_ref == rtf::NO_NODE) return;
+    struct Item { uint32_t ref; Box box; };
+    std::vector<Item> stack{{bvh.root_ref, bvh.root_box}};
+    while (!stack.empty()) {
+        Item it = stack.back();
+        stack.pop_back();
+        for (int i = 0; i < 3; i++) { boxes.push_back(it.box.lo[i]); boxes.push_back(it.box.hi[i]); }
+        if (it.ref & rtf::LEAF_BIT) {
+            uint32_t first = it.ref & rtf::LEAF_FIRST_MASK, cnt = (it.ref >> rtf::LEAF_COUNT_SHIFT) & 15;
+            rec.push_back(1);
+            rec.push_back((int32_t)cnt);
+            for (uint32_t k = 0; k < cnt; k++) rec.push_back((int32_t)bvh.prims[first + k].id);
+        } else {
+            const rtf::Node<double>& nd = bvh.nodes[it.ref];
+            rec.push_back(0);
+            rec.push_back(0);
+            Item a{nd.c0, {}}, c{nd.c1, {}};
+            for (int i = 0; i < 3; i++) { a.box.lo[i] = nd.lo0[i]; a.box.hi[i] = nd.hi0[i]; c.box.lo[i] = nd.lo1[i]; c.box.hi[i] = nd.hi1[i]; }
+            stack.push_back(c);   // pre-order: child 0 first
+            stack.push_back(a);
+        }
+    }
+}
+
+std::vector<rtf::Node<float>> to_f32(const std::vector<rtf::Node<double>>& n)
+{
+    std::vector<rtf::Node<float>> o(n.size());
+    for (size_t k = 0; k < n.size(); k++) {
+        for (int i = 0; i < 3; i++) {
+            o[k].lo0[i] = (float)n[k].lo0[i]; o[k].hi0[i] = (float)n[k].hi0[i];
+            o[k].lo1[i] = (float)n[k].lo1[i]; o[k].hi1[i] = (float)n[k].hi1[i];
+        }
+        o[k].c0 = n[k].c0;
+        o[k].c1 = n[k].c1;
+    }
+    return o;
+}
+
+std::vector<rtf::Prim<float>> to_f32(const std::vector<rtf::Prim<double>>& p)
+{
+    std::vector<rtf::Prim<float>> o(p.size());
+    for (size_t k = 0; k < p.size(); k++) {
+        for (int i = 0; i < 3; i++) { o[k].a[i] = (float)p[k].a[i]; o[k].e1[i] = (float)p[k].e1[i]; o[k].e2[i] = (float)p[k].e2[i]; }
+        o[k].id = p[k].id;
+        o[k].kind = p[k].kind;
+    }
+    return o;
+}
+
+// ---------------------------------------------------------------- BMP writer (IO.cpp:5-68)
+void quantize_bgr8(int64_t n_px, const double* rgb, uint8_t* bgr)
+{
+    for (int64_t i = 0; i < n_px; i++) {       // (unsigned char) floor(v * 255), B G R (IO.cpp:58-62)
+        bgr[3 * i] = (unsigned char)floor(rgb[3 * i + 2] * 255);
+        bgr[3 * i + 1] = (unsigned char)floor(rgb[3 * i + 1] * 255);
+        bgr[3 * i + 2] = (unsigned char)floor(rgb[3 * i] * 255);
+    }
+}
+
+int save_bmp_bgr8(const char* path, int w, int h, int dpi, const uint8_t* bgr)
+{
+    // The reference's header, field for field: bfSize counts 4 bytes per pixel, the image-size
+    // field starts at info-header byte 21 (one early), pixels-per-metre at 25 and 29; 24 bpp rows
+    // are written bottom-up without padding.
+    uint32_t pixels = (uint32_t)w * (uint32_t)h;
+    uint32_t img = 4u * pixels, file_size = 54u + img, ppm = (uint32_t)(dpi * 39);
+    unsigned char head[54];
+    memset(head, 0, sizeof head);
+    head[0] = 'B'; head[1] = 'M'; head[10] = 54;
+    unsigned char* info = head + 14;
+    info[0] = 40; info[12] = 1; info[14] = 24;
+    auto put = [](unsigned char* p, uint32_t v) { for (int i = 0; i < 4; i++) p[i] = (unsigned char)(v >> (8 * i)); };
+    put(head + 2, file_size);
+    put(info + 4, (uint32_t)w);
+    put(info + 8, (uint32_t)h);
+    put(info + 21, img);
+    put(info + 25, ppm);
+    put(info + 29, ppm);
+    FILE* f = fopen(path, "wb");
+    if (!f) return -1;
+    bool ok = fwrite(head, 1, 54, f) == 54 && fwrite(bgr, 1, (size_t)pixels * 3, f) == (size_t)pixels * 3;
+    fclose(f);
+    return ok ? 0 : -1;
+}
+
+}  // namespace rth

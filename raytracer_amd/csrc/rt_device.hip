@@ -1,0 +1,521 @@
+// C ABI implementation: contexts, scene upload and kernel launches (see include/rt_amd.h).
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_amd.h"
+#include "host_scene.h"
+#include "rt_flat.h"
+#include "rt_kernels.hip.h"
+#include "rt_math.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t n)
+    {
+        if (n <= bytes) return RT_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        hipError_t e = hipMalloc(&p, n ? n : 16);
+        if (e != hipSuccess) return fail(RT_ERR_HIP, "hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+        bytes = n;
+        return RT_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+template <class T>
+int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
+{
+    int rc = b.reserve(std::max<size_t>(v.size() * sizeof(T), 64));
+    if (rc) return rc;
+    if (!v.empty()) HIP_TRY(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return RT_OK;
+}
+
+}  // namespace
+
+struct rt_scene {
+    rth::Scene s;
+};
+
+struct rt_context {
+    int device = 0;
+    int num_cus = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // flattened scene in HBM, both instantiations
+    DevBuf nodes64, prims64, planes64, nodes32, prims32, planes32, objs, texdesc, texels;
+    rtf::SceneView<double> v64{};
+    rtf::SceneView<float> v32{};
+    int depth = 0;
+    int n_objects = 0;
+    bool has_scene = false;
+    DevBuf counters;          // rtk::TraceCounters
+    // staging for the host-buffer convenience entry points
+    DevBuf st_org, st_dir, st_dist, st_ids, st_aux;
+};
+
+namespace {
+
+int use_device(rt_context* ctx)
+{
+    HIP_TRY(hipSetDevice(ctx->device));
+    return RT_OK;
+}
+
+int stack_cap(const rt_context* ctx) { return ctx->depth + 2; }
+
+template <class R>
+const rtf::SceneView<R>& view(const rt_context* ctx);
+template <> const rtf::SceneView<double>& view<double>(const rt_context* ctx) { return ctx->v64; }
+template <> const rtf::SceneView<float>& view<float>(const rt_context* ctx) { return ctx->v32; }
+
+int grid_blocks(const rt_context* ctx, size_t lds_bytes)
+{
+    // persistent grid: as many 256-thread blocks as stay resident (LDS- and wave-limited), capped at 8 per CU
+    int per_cu = 8;
+    if (lds_bytes > 0) per_cu = std::min<int>(per_cu, (int)((160 * 1024) / lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    return ctx->num_cus * per_cu;
+}
+
+int read_counters(rt_context* ctx, rtk::TraceCounters* out)
+{
+    HIP_TRY(hipMemcpyAsync(out, ctx->counters.p, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+template <class R>
+int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* d_dir, double* d_dist, int32_t* d_ids)
+{
+    int cap = stack_cap(ctx);
+    size_t lds = rtk::stack_lds_bytes(cap, sizeof(R));
+    if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
+    int blocks = (int)std::min<int64_t>(grid_blocks(ctx, lds), (n + rtk::BLOCK - 1) / rtk::BLOCK);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((rtk::trace_batch_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), (long long)n, d_org,
+                       d_dir, d_dist, d_ids, (rtk::TraceCounters*)ctx->counters.p, cap);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+template <class R>
+int launch_primary(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow)
+{
+    int cap = stack_cap(ctx);
+    size_t lds = rtk::stack_lds_bytes(cap, sizeof(R));
+    if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
+    int64_t tiles = (int64_t)((a.width + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
+    int blocks = (int)std::min<int64_t>(grid_blocks(ctx, lds), (tiles + rtk::WAVES_PER_BLOCK - 1) / rtk::WAVES_PER_BLOCK);
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((rtk::trace_primary_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a, d_ids, d_t,
+                       d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int check_params(const rt_render_params* p)
+{
+    if (!p) return fail(RT_ERR_INVALID, "params is NULL");
+    if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID, "rt_render_params.struct_size %u != %zu", p->struct_size, sizeof(rt_render_params));
+    if (p->width <= 0 || p->height <= 0) return fail(RT_ERR_INVALID, "image size %d x %d", p->width, p->height);
+    if (p->precision != RT_F64 && p->precision != RT_F32) return fail(RT_ERR_INVALID, "precision %d", p->precision);
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+const char* rt_last_error(void) { return g_err.c_str(); }
+
+int rt_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_context_create(int device, rt_context** out)
+{
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(RT_ERR_NO_DEVICE, "no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(RT_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(RT_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RT_ERR_NO_DEVICE, "device %d is %s; this library carries gfx950 code only", device, prop.gcnArchName);
+    rt_context* ctx = new rt_context();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return fail(RT_ERR_NO_DEVICE, "cannot create a stream on device %d", device);
+    }
+    for (auto& ev : ctx->ev)
+        if (hipEventCreate(&ev) != hipSuccess) { delete ctx; return fail(RT_ERR_HIP, "hipEventCreate failed"); }
+    int rc = ctx->counters.reserve(256);
+    if (rc) { delete ctx; return rc; }
+    *out = ctx;
+    return RT_OK;
+}
+
+void rt_context_destroy(rt_context* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
+                      &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux})
+        b->release();
+    for (auto& ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void* rt_context_stream(rt_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int rt_context_synchronize(rt_context* ctx)
+{
+    if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+void rt_default_params(rt_render_params* p)
+{
+    memset(p, 0, sizeof(*p));
+    p->struct_size = sizeof(*p);
+    p->width = 512; p->height = 512;    // main.cpp:606-607
+    p->aadepth = 1;                     // main.cpp:610
+    p->tracing_depth = 4;               // main.cpp:28
+    p->photon_num = 50000;              // main.cpp:21
+    p->photon_use = 1000;               // main.cpp:22
+    p->head_quirk = 0;
+    p->use_photon_map = 1;
+    p->precision = RT_F64;
+    p->shadow_rays = 0;
+    p->accuracy = 0.000001;             // main.cpp:614
+    p->photon_dist = 0.28;              // Kdtree.cpp:6
+    p->light_pos[0] = 0.1; p->light_pos[1] = 0.2; p->light_pos[2] = 0;   // main.cpp:654
+}
+
+void rt_camera_look_at(const double pos[3], const double look_at[3], rt_camera* out)
+{
+    // main.cpp:626-635
+    rtm::D3 Y = {0, 1, 0};
+    rtm::D3 diff = {pos[0] - look_at[0], pos[1] - look_at[1], pos[2] - look_at[2]};
+    rtm::D3 dir = rtm::vnorm(rtm::vneg(diff));
+    rtm::D3 right = rtm::vnorm(rtm::vcross(Y, dir));
+    rtm::D3 down = rtm::vcross(right, dir);
+    for (int i = 0; i < 3; i++) out->pos[i] = pos[i];
+    out->dir[0] = dir.x; out->dir[1] = dir.y; out->dir[2] = dir.z;
+    out->right[0] = right.x; out->right[1] = right.y; out->right[2] = right.z;
+    out->down[0] = down.x; out->down[1] = down.y; out->down[2] = down.z;
+}
+
+// ---------------------------------------------------------------- host scene
+int rt_scene_create(rt_scene** out)
+{
+    if (!out) return fail(RT_ERR_INVALID, "out is NULL");
+    *out = new rt_scene();
+    return RT_OK;
+}
+void rt_scene_destroy(rt_scene* s) { delete s; }
+int rt_scene_size(const rt_scene* s) { return s ? (int)s->s.objects.size() : 0; }
+
+int rt_scene_add_triangle(rt_scene* s, const double A[3], const double C[3], const double B[3], const double rgbs[4], float ior)
+{
+    if (!s || !A || !B || !C || !rgbs) return fail(RT_ERR_INVALID, "null argument");
+    return s->s.add_triangle(A, C, B, rgbs, ior);
+}
+int rt_scene_set_normals(rt_scene* s, int obj, const double na[3], const double nc[3], const double nb[3])
+{
+    if (!s || !na || !nb || !nc) return fail(RT_ERR_INVALID, "null argument");
+    return s->s.set_normals(obj, na, nc, nb) ? fail(RT_ERR_INVALID, "object %d is not a triangle", obj) : RT_OK;
+}
+int rt_scene_set_texture(rt_scene* s, int obj, const double ta[2], const double tc[2], const double tb[2], int use_texture, int map)
+{
+    if (!s || !ta || !tb || !tc) return fail(RT_ERR_INVALID, "null argument");
+    return s->s.set_texture(obj, ta, tc, tb, use_texture, map) ? fail(RT_ERR_INVALID, "object %d is not a triangle or map %d unknown", obj, map)
+                                                                 : RT_OK;
+}
+int rt_scene_add_sphere(rt_scene* s, const double center[3], double radius, const double rgbs[4], float ior)
+{
+    if (!s || !center || !rgbs) return fail(RT_ERR_INVALID, "null argument");
+    return s->s.add_sphere(center, radius, rgbs, ior);
+}
+int rt_scene_add_plane(rt_scene* s, const double normal[3], double distance, const double rgbs[4])
+{
+    if (!s || !normal || !rgbs) return fail(RT_ERR_INVALID, "null argument");
+    return s->s.add_plane(normal, distance, rgbs);
+}
+int rt_scene_add_cornell_box(rt_scene* s, const double corner1[3], const double corner2[3])
+{
+    if (!s || !corner1 || !corner2) return fail(RT_ERR_INVALID, "null argument");
+    s->s.add_cornell_box(corner1, corner2);
+    return RT_OK;
+}
+int rt_scene_add_cube(rt_scene* s, const double corner1[3], const double corner2[3], const double rgbs[4])
+{
+    if (!s || !corner1 || !corner2 || !rgbs) return fail(RT_ERR_INVALID, "null argument");
+    s->s.add_cube(corner1, corner2, rgbs);
+    return RT_OK;
+}
+int rt_scene_load_obj(rt_scene* s, const char* path, const double rgbs[4], float ior, float xoff, float yoff, float zoff, int use_texture,
+                      int map)
+{
+    if (!s || !path || !rgbs) return fail(RT_ERR_INVALID, "null argument");
+    int rc = s->s.load_obj(path, rgbs, ior, xoff, yoff, zoff, use_texture, map);
+    if (rc == -1) return fail(RT_ERR_IO, "cannot open %s", path);
+    if (rc) return fail(RT_ERR_IO, "bad vertex index in %s", path);
+    return RT_OK;
+}
+int rt_scene_add_texture_bmp(rt_scene* s, const char* path)
+{
+    if (!s || !path) return fail(RT_ERR_INVALID, "null argument");
+    int rc = s->s.add_texture_bmp(path);
+    return rc < 0 ? fail(RT_ERR_IO, "cannot read texture %s", path) : rc;
+}
+int rt_scene_add_texture_rgb(rt_scene* s, int x_res, int y_res, const double* rgb)
+{
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    int rc = s->s.add_texture_rgb(x_res, y_res, rgb);
+    return rc < 0 ? fail(RT_ERR_INVALID, "bad texture") : rc;
+}
+int rt_scene_build_bvh(rt_scene* s)
+{
+    if (!s) return fail(RT_ERR_INVALID, "null argument");
+    s->s.build_bvh();
+    return RT_OK;
+}
+int rt_scene_bvh_dump(const rt_scene* s, int32_t* rec, int64_t* n_rec, double* boxes, int64_t* n_boxes)
+{
+    if (!s || !n_rec || !n_boxes) return fail(RT_ERR_INVALID, "null argument");
+    if (!s->s.bvh.built) return fail(RT_ERR_STATE, "rt_scene_build_bvh has not been called");
+    std::vector<int32_t> r;
+    std::vector<double> b;
+    s->s.bvh_dump(r, b);
+    if (rec && boxes) {
+        if (*n_rec < (int64_t)r.size() || *n_boxes < (int64_t)b.size() / 6) return fail(RT_ERR_INVALID, "buffers too small");
+        memcpy(rec, r.data(), r.size() * sizeof(int32_t));
+        memcpy(boxes, b.data(), b.size() * sizeof(double));
+    }
+    *n_rec = (int64_t)r.size();
+    *n_boxes = (int64_t)b.size() / 6;
+    return RT_OK;
+}
+int rt_scene_bvh_depth(const rt_scene* s) { return (s && s->s.bvh.built) ? s->s.bvh.depth : -1; }
+
+// ---------------------------------------------------------------- device scene
+int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
+{
+    if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
+    const rth::Scene& s = scene->s;
+    if (!s.bvh.built) return fail(RT_ERR_STATE, "rt_scene_build_bvh has not been called");
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const rth::FlatBVH& b = s.bvh;
+    auto n32 = rth::to_f32(b.nodes);
+    auto p32 = rth::to_f32(b.prims);
+    auto pl32 = rth::to_f32(b.planes);
+    if ((rc = upload(ctx->nodes64, b.nodes, ctx->stream))) return rc;
+    if ((rc = upload(ctx->prims64, b.prims, ctx->stream))) return rc;
+    if ((rc = upload(ctx->planes64, b.planes, ctx->stream))) return rc;
+    if ((rc = upload(ctx->nodes32, n32, ctx->stream))) return rc;
+    if ((rc = upload(ctx->prims32, p32, ctx->stream))) return rc;
+    if ((rc = upload(ctx->planes32, pl32, ctx->stream))) return rc;
+    std::vector<rtf::ObjShade> sh(s.objects.size());
+    for (size_t i = 0; i < sh.size(); i++) sh[i] = s.objects[i].sh;
+    if ((rc = upload(ctx->objs, sh, ctx->stream))) return rc;
+    std::vector<rtf::TexDesc> td;
+    std::vector<double> pool;
+    for (const auto& t : s.textures) {
+        td.push_back({t.x_res, t.y_res, (int64_t)pool.size()});
+        pool.insert(pool.end(), t.rgb.begin(), t.rgb.end());
+    }
+    if ((rc = upload(ctx->texdesc, td, ctx->stream))) return rc;
+    if ((rc = upload(ctx->texels, pool, ctx->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the host vectors above die at return
+
+    ctx->v64.nodes = (const rtf::Node<double>*)ctx->nodes64.p;
+    ctx->v64.prims = (const rtf::Prim<double>*)ctx->prims64.p;
+    ctx->v64.planes = (const rtf::Prim<double>*)ctx->planes64.p;
+    ctx->v32.nodes = (const rtf::Node<float>*)ctx->nodes32.p;
+    ctx->v32.prims = (const rtf::Prim<float>*)ctx->prims32.p;
+    ctx->v32.planes = (const rtf::Prim<float>*)ctx->planes32.p;
+    for (int i = 0; i < 3; i++) {
+        ctx->v64.root_lo[i] = b.root_box.lo[i]; ctx->v64.root_hi[i] = b.root_box.hi[i];
+        ctx->v32.root_lo[i] = (float)b.root_box.lo[i]; ctx->v32.root_hi[i] = (float)b.root_box.hi[i];
+    }
+    ctx->v64.root_ref = ctx->v32.root_ref = b.root_ref;
+    ctx->v64.n_planes = ctx->v32.n_planes = (int32_t)b.planes.size();
+    ctx->depth = b.depth;
+    ctx->n_objects = (int)s.objects.size();
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_trace_closest_dev(rt_context* ctx, int precision, int64_t n, const double* d_org, const double* d_dir, double* d_dist, int32_t* d_ids)
+{
+    if (!ctx || !d_org || !d_dir || !d_dist || !d_ids) return fail(RT_ERR_INVALID, "null argument");
+    if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
+    if (n <= 0) return RT_OK;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (precision == RT_F64) return launch_batch<double>(ctx, n, d_org, d_dir, d_dist, d_ids);
+    if (precision == RT_F32) return launch_batch<float>(ctx, n, d_org, d_dir, d_dist, d_ids);
+    return fail(RT_ERR_INVALID, "precision %d", precision);
+}
+
+int rt_trace_closest(rt_context* ctx, int precision, int64_t n, const double* org, const double* dir, double* dist, int32_t* ids)
+{
+    if (!ctx || !org || !dir || !dist || !ids) return fail(RT_ERR_INVALID, "null argument");
+    if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
+    if (n <= 0) return RT_OK;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    // AoS (n x 3) -> SoA
+    std::vector<double> so((size_t)3 * n), sd((size_t)3 * n);
+    for (int64_t i = 0; i < n; i++)
+        for (int c = 0; c < 3; c++) { so[(size_t)c * n + i] = org[3 * i + c]; sd[(size_t)c * n + i] = dir[3 * i + c]; }
+    if ((rc = ctx->st_org.reserve(so.size() * 8))) return rc;
+    if ((rc = ctx->st_dir.reserve(sd.size() * 8))) return rc;
+    if ((rc = ctx->st_dist.reserve((size_t)n * 8))) return rc;
+    if ((rc = ctx->st_ids.reserve((size_t)n * 4))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->st_org.p, so.data(), so.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->st_dir.p, sd.data(), sd.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->st_dist.p, dist, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = rt_trace_closest_dev(ctx, precision, n, (const double*)ctx->st_org.p, (const double*)ctx->st_dir.p, (double*)ctx->st_dist.p,
+                              (int32_t*)ctx->st_ids.p);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(dist, ctx->st_dist.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ids, ctx->st_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    rtk::TraceCounters c;
+    if ((rc = read_counters(ctx, &c))) return rc;
+    if (c.overflow) return fail(RT_ERR_LIMIT, "traversal stack overflow");
+    return RT_OK;
+}
+
+int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end, int32_t* d_ids,
+                         double* d_t, int32_t* d_shadow_ids, rt_stats* stats)
+{
+    if (!ctx || !cam || !d_ids) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
+    if (row_begin < 0 || row_end > p->height || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, p->height);
+    if (p->aadepth != 1) return fail(RT_ERR_INVALID, "rt_trace_primary handles aadepth 1 only");
+    if ((rc = use_device(ctx))) return rc;
+    rtk::PrimaryArgs a;
+    for (int i = 0; i < 3; i++) {
+        a.cam_pos[i] = cam->pos[i]; a.cam_dir[i] = cam->dir[i]; a.cam_right[i] = cam->right[i]; a.cam_down[i] = cam->down[i];
+        a.light[i] = p->light_pos[i];
+    }
+    a.width = p->width; a.height = p->height; a.row_begin = row_begin; a.row_end = row_end;
+    a.shadow = p->shadow_rays ? 1 : 0;
+    HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    rc = p->precision == RT_F64 ? launch_primary<double>(ctx, a, d_ids, d_t, d_shadow_ids) : launch_primary<float>(ctx, a, d_ids, d_t, d_shadow_ids);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (stats) {
+        rtk::TraceCounters c;
+        if ((rc = read_counters(ctx, &c))) return rc;
+        if (c.overflow) return fail(RT_ERR_LIMIT, "traversal stack overflow");
+        memset(stats, 0, sizeof(*stats));
+        stats->primary_rays = (uint64_t)p->width * (uint64_t)(row_end - row_begin);
+        stats->shadow_rays = c.shadow;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        stats->kernel_ms = ms;
+        stats->trace_kernel_ms = ms;
+    }
+    return RT_OK;
+}
+
+int rt_trace_primary(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end, int32_t* ids, double* t,
+                     int32_t* shadow_ids, rt_stats* stats)
+{
+    if (!ctx || !ids) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (row_begin < 0 || row_end > p->height || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, p->height);
+    if ((rc = use_device(ctx))) return rc;
+    size_t n = (size_t)p->width * (row_end - row_begin);
+    if ((rc = ctx->st_ids.reserve(n * 4))) return rc;
+    if ((rc = ctx->st_dist.reserve(n * 8))) return rc;
+    if ((rc = ctx->st_aux.reserve(n * 4))) return rc;
+    rt_stats local;
+    rc = rt_trace_primary_dev(ctx, cam, p, row_begin, row_end, (int32_t*)ctx->st_ids.p, t ? (double*)ctx->st_dist.p : nullptr,
+                              (shadow_ids && p->shadow_rays) ? (int32_t*)ctx->st_aux.p : nullptr, &local);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ids, ctx->st_ids.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (t) HIP_TRY(hipMemcpyAsync(t, ctx->st_dist.p, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (shadow_ids && p->shadow_rays) HIP_TRY(hipMemcpyAsync(shadow_ids, ctx->st_aux.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (stats) *stats = local;
+    return RT_OK;
+}
+
+// ---------------------------------------------------------------- not built yet
+int rt_photons_upload(rt_context*, int, int64_t, const double*) { return fail(RT_ERR_STATE, "photon map path not built in this library version"); }
+int rt_knn_radius(rt_context*, int, int, double, int64_t, const double*, int32_t*, double*) { return fail(RT_ERR_STATE, "photon map path not built in this library version"); }
+int rt_knn_estimate(rt_context*, const rt_render_params*, int64_t, const double*, const double*, const double*, double*, int32_t*) { return fail(RT_ERR_STATE, "photon map path not built in this library version"); }
+int rt_render_rows_dev(rt_context*, const rt_camera*, const rt_render_params*, int, int, double*, uint8_t*, rt_stats*) { return fail(RT_ERR_STATE, "render path not built in this library version"); }
+int rt_render_rows(rt_context*, const rt_camera*, const rt_render_params*, int, int, double*, uint8_t*, rt_stats*) { return fail(RT_ERR_STATE, "render path not built in this library version"); }
+
+// ---------------------------------------------------------------- host I/O
+int rt_save_bmp(const char* path, int w, int h, int dpi, const double* rgb)
+{
+    if (!path || !rgb || w <= 0 || h <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    std::vector<uint8_t> bgr((size_t)w * h * 3);
+    rth::quantize_bgr8((int64_t)w * h, rgb, bgr.data());
+    return rth::save_bmp_bgr8(path, w, h, dpi, bgr.data()) ? fail(RT_ERR_IO, "cannot write %s", path) : RT_OK;
+}
+int rt_save_bmp_bgr8(const char* path, int w, int h, int dpi, const uint8_t* bgr)
+{
+    if (!path || !bgr || w <= 0 || h <= 0) return fail(RT_ERR_INVALID, "bad argument");
+    return rth::save_bmp_bgr8(path, w, h, dpi, bgr) ? fail(RT_ERR_IO, "cannot write %s", path) : RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// HIP kernels of the closest-hit path (gfx950, wave64).  Included by rt_device.hip only.
+//
+// K2  closest-hit traversal = BVH::Shoot (BVH.cpp:108-179) + the primitive tests, one ray per lane,
+//     persistent waves pulling 64-ray chunks / 8x8 pixel tiles from an atomic counter, per-lane
+//     traversal stack in LDS laid out [depth][lane] (bank = lane, conflict free).
+// K1  primary-ray generation (main.cpp:753-790) is fused into the primary-ray kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_flat.h"
+#include "rt_math.h"
+
+namespace rtk {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+
+struct LaneStack {
+    uint32_t* ref;   // [depth][64] for this wave
+    void* t0;        // [depth][64] of R
+    int lane;
+    int cap;
+};
+
+template <class R> __device__ __forceinline__ bool rt_finite(R v);
+template <> __device__ __forceinline__ bool rt_finite<float>(float v) { return __builtin_isfinite(v); }
+template <> __device__ __forceinline__ bool rt_finite<double>(double v) { return __builtin_isfinite(v); }
+
+// Leaf: test every primitive in leaf order, accept iff t >= 0 && t < dist (BVH.cpp:135-149).
+template <class R>
+__device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims, uint32_t leaf, const R* o, const R* d, R& dist, int& hit)
+{
+    uint32_t first = leaf & rtf::LEAF_FIRST_MASK;
+    uint32_t cnt = (leaf >> rtf::LEAF_COUNT_SHIFT) & 15u;
+    for (uint32_t k = 0; k < cnt; k++) {
+        const rtf::Prim<R>& p = prims[first + k];
+        R t = rtm::prim_intersect<R>(p, o, d);
+        if (t >= R(0) && t < dist) { dist = t; hit = (int)p.id; }
+    }
+}
+
+// BVH::Shoot for one ray.  `dist` is in/out exactly like the reference's `distance`.
+// Visiting order, tie handling and culling are the reference's:
+//   - both child boxes are tested against the current best (BVH.cpp:155-156), the child with the
+//     smaller entry distance is entered first (child 1 on ties, BVH.cpp:159-176);
+//   - the reference re-tests a child's box when it enters it.  For the child entered first nothing
+//     has changed, so the re-test is skipped; for the deferred child the only thing that can have
+//     changed is `dist`, and for finite operands the re-test then fails iff t0 > dist, which is
+//     what the pop compares (t0 travels on the stack);
+//   - rays with a non-finite reciprocal direction or origin (axis-parallel rays: 0 * inf = NaN in
+//     the slab test) take the literal path below, which re-runs the full slab test on entry.
+template <class R>
+__device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R& dist, const LaneStack& st, uint32_t* overflow)
+{
+    if (d[0] != d[0]) return -1;   // BVH.cpp:110-115
+    int hit = -1;
+    uint32_t* s_ref = st.ref;
+    R* s_t0 = (R*)st.t0;
+    const int lane = st.lane;
+
+    if (sv.root_ref != rtf::NO_NODE) {
+        R inv[3] = {R(1) / d[0], R(1) / d[1], R(1) / d[2]};
+        bool finite = rt_finite<R>(inv[0]) && rt_finite<R>(inv[1]) && rt_finite<R>(inv[2]) && rt_finite<R>(o[0]) && rt_finite<R>(o[1]) &&
+                      rt_finite<R>(o[2]) && rt_finite<R>(dist);
+        if (finite) {
+            if (!(rtm::slab_finite<R>(sv.root_lo, sv.root_hi, o, inv, dist) < R(0))) {   // BVH.cpp:121,132
+                uint32_t cur = sv.root_ref;
+                int sp = 0;
+                while (true) {
+                    if (!(cur & rtf::LEAF_BIT)) {
+                        const rtf::Node<R>& nd = sv.nodes[cur];
+                        R td0 = rtm::slab_finite<R>(nd.lo0, nd.hi0, o, inv, dist);
+                        R td1 = rtm::slab_finite<R>(nd.lo1, nd.hi1, o, inv, dist);
+                        uint32_t c0 = nd.c0, c1 = nd.c1;
+                        bool h0 = !(td0 < R(0)), h1 = !(td1 < R(0));
+                        if (h0 && h1) {
+                            bool first0 = td0 < td1;
+                            if (sp < st.cap) {
+                                s_ref[sp * WAVE + lane] = first0 ? c1 : c0;
+                                s_t0[sp * WAVE + lane] = first0 ? td1 : td0;
+                                sp++;
+                            } else {
+                                *overflow = 1;
+                            }
+                            cur = first0 ? c0 : c1;
+                            continue;
+                        }
+                        if (h0) { cur = c0; continue; }
+                        if (h1) { cur = c1; continue; }
+                    } else {
+                        test_leaf<R>(sv.prims, cur, o, d, dist, hit);
+                    }
+                    bool found = false;
+                    while (sp > 0) {
+                        sp--;
+                        R t0 = s_t0[sp * WAVE + lane];
+                        if (!(t0 > dist)) { cur = s_ref[sp * WAVE + lane]; found = true; break; }
+                    }
+                    if (!found) break;
+                }
+            }
+        } else {
+            // literal emulation of the recursion; stack entries are (parent node << 1 | which child)
+            if (!(rtm::slab_literal<R>(sv.root_lo, sv.root_hi, o, d, dist) < R(0))) {
+                int sp = 0;
+                uint32_t cur = sv.root_ref;
+                bool have = true;
+                while (true) {
+                    if (have) {
+                        if (cur & rtf::LEAF_BIT) {
+                            test_leaf<R>(sv.prims, cur, o, d, dist, hit);
+                        } else {
+                            const rtf::Node<R>& nd = sv.nodes[cur];
+                            R td0 = rtm::slab_literal<R>(nd.lo0, nd.hi0, o, d, dist);
+                            R td1 = rtm::slab_literal<R>(nd.lo1, nd.hi1, o, d, dist);
+                            uint32_t first = td0 < td1 ? 0u : 1u;
+                            if (sp + 2 <= st.cap) {
+                                s_ref[sp * WAVE + lane] = (cur << 1) | (1u - first);
+                                sp++;
+                                s_ref[sp * WAVE + lane] = (cur << 1) | first;
+                                sp++;
+                            } else {
+                                *overflow = 1;
+                            }
+                        }
+                    }
+                    if (sp == 0) break;
+                    sp--;
+                    uint32_t e = s_ref[sp * WAVE + lane];
+                    const rtf::Node<R>& pn = sv.nodes[e >> 1];
+                    bool second = e & 1u;
+                    const R* lo = second ? pn.lo1 : pn.lo0;
+                    const R* hi = second ? pn.hi1 : pn.hi0;
+                    have = !(rtm::slab_literal<R>(lo, hi, o, d, dist) < R(0));   // entry test, BVH.cpp:132
+                    cur = second ? pn.c1 : pn.c0;
+                }
+            }
+        }
+    }
+    // planes: side list, same accept rule (no counterpart in the reference, where Plane is abstract)
+    for (int k = 0; k < sv.n_planes; k++) {
+        const rtf::Prim<R>& p = sv.planes[k];
+        R t = rtm::plane_intersect<R>(p.a, p.e1[0], o, d);
+        if (t >= R(0) && t < dist) { dist = t; hit = (int)p.id; }
+    }
+    return hit;
+}
+
+__device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* counter, unsigned long long amount, int lane)
+{
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(counter, amount);
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
+    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+template <class R>
+__device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap)
+{
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    LaneStack st;
+    st.ref = (uint32_t*)lds + (size_t)wave * cap * WAVE;
+    st.t0 = (void*)((R*)(lds + (size_t)WAVES_PER_BLOCK * cap * WAVE * sizeof(uint32_t)) + (size_t)wave * cap * WAVE);
+    st.lane = lane;
+    st.cap = cap;
+    return st;
+}
+
+inline size_t stack_lds_bytes(int cap, size_t real_size) { return (size_t)WAVES_PER_BLOCK * cap * WAVE * (sizeof(uint32_t) + real_size); }
+
+// counters[0] = work counter, counters[1] = stack-overflow flag, counters[2] = shadow rays traced
+struct TraceCounters { unsigned long long next; unsigned long long overflow; unsigned long long shadow; unsigned long long pad; };
+
+// Batch form of BVH::Shoot: rays in SoA doubles (x[n], y[n], z[n]).
+template <class R>
+__global__ __launch_bounds__(BLOCK) void trace_batch_kernel(rtf::SceneView<R> sv, long long n, const double* __restrict__ org,
+                                                            const double* __restrict__ dir, double* __restrict__ dist_io,
+                                                            int* __restrict__ ids, TraceCounters* ctr, int cap)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    LaneStack st = make_stack<R>(lds, cap);
+    uint32_t overflow = 0;
+    while (true) {
+        unsigned long long base = wave_fetch(&ctr->next, WAVE, st.lane);
+        if (base >= (unsigned long long)n) break;
+        long long i = (long long)base + st.lane;
+        if (i < n) {
+            R o[3] = {(R)org[i], (R)org[n + i], (R)org[2 * n + i]};
+            R d[3] = {(R)dir[i], (R)dir[n + i], (R)dir[2 * n + i]};
+            R dist = (R)dist_io[i];
+            int id = trace_ray<R>(sv, o, d, dist, st, &overflow);
+            ids[i] = id;
+            if (id >= 0) dist_io[i] = (double)dist;
+        }
+    }
+    if (overflow) atomicMax(&ctr->overflow, 1ull);
+}
+
+struct PrimaryArgs {
+    double cam_pos[3], cam_dir[3], cam_right[3], cam_down[3];
+    double light[3];
+    int width, height, row_begin, row_end;
+    int shadow;
+};
+
+// Pixel loop front end: camera ray (always generated in double, then rounded to R) + BVH::Shoot
+// with distance 1e9 (main.cpp:812-813); optional shadow ray toward the light.
+// Work unit = 8x8 pixel tile per wave.
+template <class R>
+__global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> sv, PrimaryArgs a, int* __restrict__ ids,
+                                                              double* __restrict__ t_out, int* __restrict__ shadow_ids,
+                                                              TraceCounters* ctr, int cap)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    LaneStack st = make_stack<R>(lds, cap);
+    uint32_t overflow = 0;
+    unsigned long long n_shadow = 0;
+    const int rows = a.row_end - a.row_begin;
+    const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
+    const unsigned long long n_tiles = (unsigned long long)tiles_x * tiles_y;
+    while (true) {
+        unsigned long long tile = wave_fetch(&ctr->next, 1, st.lane);
+        if (tile >= n_tiles) break;
+        int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+        int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
+        if (x < a.width && yl < rows) {
+            int y = a.row_begin + yl;
+            rtm::D3 dd = rtm::camera_ray_dir(a.cam_dir, a.cam_right, a.cam_down, a.width, a.height, 1, x, y, 0);
+            R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
+            R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
+            R dist = R(1e9);
+            int id = trace_ray<R>(sv, o, d, dist, st, &overflow);
+            long long px = (long long)yl * a.width + x;
+            ids[px] = id;
+            if (t_out) t_out[px] = (double)dist;
+            if (a.shadow) {
+                int sid = -2;
+                if (id >= 0) {
+                    // occlusion query toward the light through the same BVH::Shoot semantics:
+                    // P = o + d * t; L = normalize(light - P); origin = P + L * 1e-4; range = |light - P| - 1e-4
+                    double t = (double)dist;
+                    rtm::D3 P = rtm::vadd(rtm::D3{a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]}, rtm::vmul(dd, t));
+                    rtm::D3 Lv = rtm::vsub(rtm::D3{a.light[0], a.light[1], a.light[2]}, P);
+                    double len = sqrt(rtm::vdot(Lv, Lv));
+                    rtm::D3 L = {Lv.x / len, Lv.y / len, Lv.z / len};
+                    rtm::D3 so = rtm::vadd(P, rtm::vmul(L, 1e-4));
+                    R o2[3] = {(R)so.x, (R)so.y, (R)so.z};
+                    R d2[3] = {(R)L.x, (R)L.y, (R)L.z};
+                    R range = (R)(len - 1e-4);
+                    sid = trace_ray<R>(sv, o2, d2, range, st, &overflow);
+                    n_shadow++;
+                }
+                if (shadow_ids) shadow_ids[px] = sid;
+            }
+        }
+    }
+    if (overflow) atomicMax(&ctr->overflow, 1ull);
+    if (a.shadow) {
+        // one atomic per wave
+        for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
+        if (st.lane == 0 && n_shadow) atomicAdd(&ctr->shadow, n_shadow);
+    }
+}
+
+}  // namespace rtk

@@ -1,0 +1,145 @@
+"""GPU parity of the closest-hit path (through the C ABI) against the CPU oracle and the golden
+vectors of the compiled reference.  f64 instantiation: ids and t bit-exact."""
+import hashlib
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from conftest import CAM, build_scene, golden, golden_hashes
+from oracle.bindings import Oracle, id_map_hash
+
+pytestmark = pytest.mark.gpu
+
+
+def eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def scenes(gpu_ctx):
+    out = {}
+    for tag in ["teapot_normal", "water"]:
+        out[tag] = build_scene(rt.Scene(), tag + ".obj")
+    return out
+
+
+@pytest.mark.parametrize("tag", ["teapot_normal", "water"])
+def test_batch_rays_bit_exact(gpu_ctx, scenes, tag):
+    gpu_ctx.upload(scenes[tag])
+    g = golden(f"rays_{tag}.npz")
+    ids, t = gpu_ctx.trace_closest(g["org"], g["dir"])
+    assert eq(ids, g["ids"]) and eq(t, g["t"])
+    ids, t = gpu_ctx.trace_closest(g["org"], g["dir"], g["max_dist"])
+    assert eq(ids, g["ids_bounded"]) and eq(t, g["t_bounded"])
+    # axis-parallel rays: zero direction components -> inf / NaN paths of the slab test
+    ids, t = gpu_ctx.trace_closest(g["org_axis"], g["dir_axis"])
+    assert eq(ids, g["ids_axis"]) and eq(t, g["t_axis"])
+    for sz in ["64x64", "96x54", "40x72"]:
+        h = golden(f"hits_{tag}_{sz}.npz")
+        org = np.repeat(h["org"], h["dir"].shape[0], axis=0)
+        ids, t = gpu_ctx.trace_closest(org, h["dir"])
+        assert eq(ids, h["ids"]) and eq(t, h["t"])
+
+
+@pytest.mark.parametrize("tag", ["teapot_normal", "water"])
+def test_primary_1920x1080_hash(gpu_ctx, scenes, tag):
+    """The full-size id map: hash, hit counts and sha256 of the t image equal the compiled reference's."""
+    gpu_ctx.upload(scenes[tag])
+    p = rt.default_params(width=1920, height=1080)
+    ids, t, _, st = gpu_ctx.trace_primary(rt.look_at(CAM[:3], CAM[3:]), p)
+    g = golden_hashes()[tag]
+    assert id_map_hash(ids) == g["hash"]
+    assert int((ids >= 0).sum()) == g["hits"]
+    t_ref_form = np.where(ids >= 0, t, 1e9)
+    assert hashlib.sha256(t_ref_form.tobytes()).hexdigest() == g["t_sha256"]
+    assert st.primary_rays == 1920 * 1080
+
+
+def test_primary_small_sizes_and_row_bands(gpu_ctx, scenes):
+    gpu_ctx.upload(scenes["teapot_normal"])
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    for (w, h) in [(64, 64), (96, 54), (40, 72)]:
+        g = golden(f"hits_teapot_normal_{w}x{h}.npz")
+        p = rt.default_params(width=w, height=h)
+        ids, t, _, _ = gpu_ctx.trace_primary(cam, p)
+        assert eq(ids, g["ids"])
+        assert eq(np.where(ids >= 0, t, 1e9), g["t"])
+        # ragged row band (multi-GPU tiling unit): rows [5, 23)
+        ids_b, t_b, _, _ = gpu_ctx.trace_primary(cam, p, rows=(5, 23))
+        assert eq(ids_b, g["ids"].reshape(h, w)[5:23].ravel())
+
+
+def test_shadow_rays_match_oracle(gpu_ctx, scenes):
+    """Occlusion rays (extension) go through the same Shoot semantics with a bounded range."""
+    gpu_ctx.upload(scenes["teapot_normal"])
+    orc = build_scene(Oracle(), "teapot_normal.obj")
+    w, h = 160, 90
+    light = np.array([0.1, 0.9, 0.0])
+    p = rt.default_params(width=w, height=h, shadow_rays=1, light_pos=light)
+    ids, t, sh, st = gpu_ctx.trace_primary(rt.look_at(CAM[:3], CAM[3:]), p)
+    org, d = orc.primary_rays(w, h, CAM)
+    oid, ot = orc.shoot(org, d)
+    assert eq(ids, oid)
+    hit = oid >= 0
+    P = org[hit] + d[hit] * ot[hit][:, None]
+    Lv = light - P
+    ln = np.sqrt(Lv[:, 0] * Lv[:, 0] + Lv[:, 1] * Lv[:, 1] + Lv[:, 2] * Lv[:, 2])
+    L = Lv / ln[:, None]
+    so = P + L * 1e-4
+    sid, _ = orc.shoot(so, L, ln - 1e-4)
+    exp = np.full(w * h, -2, np.int32)
+    exp[hit] = sid
+    assert eq(sh, exp)
+    assert st.shadow_rays == int(hit.sum())
+
+
+def test_mixed_primitives_and_planes(gpu_ctx):
+    """Spheres (with the reference's root quirks) inside the BVH, a plane in the side list."""
+    def fill(api):
+        r2 = np.random.default_rng(21)
+        for i in range(60):
+            A, C, B = r2.uniform(-1, 1, (3, 3))
+            api.add_triangle(A, C, B, (0.3, 0.6, 0.9, 0.0), 1.5)
+        for i in range(30):
+            api.add_sphere(r2.uniform(-0.8, 0.8, 3), float(r2.uniform(0.05, 0.4)), (1, 1, 1, 0.9), 1.5)
+        api.add_plane((0.0, 1.0, 0.0), -1.0, (0.5, 0.5, 0.5, 0))
+        api.build_bvh()
+        return api
+    s = fill(rt.Scene()); orc = fill(Oracle())
+    gpu_ctx.upload(s)
+    rng = np.random.default_rng(4)
+    org = rng.uniform(-1.5, 1.5, (20000, 3)); d = rng.normal(size=(20000, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    ids, t = gpu_ctx.trace_closest(org, d)
+    oid, ot = orc.shoot(org, d)
+    assert eq(ids, oid) and eq(t, ot)
+    assert (ids == 90).any() and ((ids >= 60) & (ids < 90)).any()
+
+
+def test_empty_and_tiny_scenes(gpu_ctx):
+    s = rt.Scene(); s.build_bvh()
+    gpu_ctx.upload(s)
+    ids, t = gpu_ctx.trace_closest(np.zeros((5, 3)), np.ones((5, 3)))
+    assert (ids == -1).all() and (t == 1e9).all()
+    s = build_scene(rt.Scene(), None)    # Cornell box only: root is a leaf
+    orc = build_scene(Oracle(), None)
+    gpu_ctx.upload(s)
+    rng = np.random.default_rng(8)
+    org = rng.uniform(-1, 1, (5000, 3)); d = rng.uniform(-1, 1, (5000, 3))
+    d[::50] = np.nan   # NaN direction -> miss (BVH.cpp:110-115)
+    ids, t = gpu_ctx.trace_closest(org, d)
+    oid, ot = orc.shoot(org, d)
+    assert eq(ids, oid) and eq(t, ot)
+
+
+def test_bvh_equals_brute_force_on_gpu(gpu_ctx, scenes):
+    """BVHSelfTest's property (BVH.cpp:220-246) with the GPU traversal on the BVH side."""
+    gpu_ctx.upload(scenes["water"])
+    orc = build_scene(Oracle(), "water.obj")
+    rng = np.random.default_rng(6)
+    org = rng.uniform(-1, 1, (4000, 3)); d = rng.uniform(-1, 1, (4000, 3))
+    ids, t = gpu_ctx.trace_closest(org, d)
+    bids, bt = orc.brute_force(org, d)
+    assert eq(t, bt)
+    assert (ids == bids).mean() > 0.999

@@ -1,0 +1,90 @@
+"""CPU-side checks of the product library: the C ABI loads and exports what include/rt_amd.h
+declares, the host BVH builder reproduces the reference's tree, host I/O matches, and compute
+entry points refuse to run without a GPU (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from raytracer_amd import _lib
+from conftest import DATA, ROOT, build_scene, golden
+
+
+def eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) > 30
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in rt_amd.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert _lib.lib.rt_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    p = rt.default_params()
+    assert p.struct_size == ctypes.sizeof(rt.RenderParams)
+    assert (p.width, p.height, p.aadepth, p.tracing_depth, p.photon_num, p.photon_use) == (512, 512, 1, 4, 50000, 1000)
+    assert p.accuracy == 1e-6 and p.photon_dist == 0.28 and list(p.light_pos) == [0.1, 0.2, 0.0]
+
+
+@pytest.mark.parametrize("tag", ["teapot_normal", "water"])
+def test_host_bvh_matches_reference_tree(tag):
+    s = build_scene(rt.Scene(), tag + ".obj")
+    g = golden(f"bvh_{tag}.npz")
+    rec, boxes = s.bvh_dump()
+    assert eq(rec, g["rec"])
+    assert eq(boxes, g["boxes"])
+
+
+def test_small_scene_root_is_leaf():
+    s = build_scene(rt.Scene(), None)   # 10 triangles < 16 -> the root stays a leaf (BVH.cpp:59)
+    rec, boxes = s.bvh_dump()
+    assert rec[0] == 1 and rec[1] == 10 and list(rec[2:]) == list(range(10))
+    assert s.bvh_depth() == 0
+    assert eq(boxes[0], [-1, 1, -1, 1, -1, 1])
+
+
+def test_tolerant_obj_loader():
+    """teapot1.obj / test.obj have `v/vt` faces; the reference crashes on them (IO.h:91-101)."""
+    s = rt.Scene()
+    s.load_obj(os.path.join(DATA, "teapot1.obj"))
+    assert s.size() == 992
+    s2 = rt.Scene()
+    s2.load_obj(os.path.join(DATA, "test.obj"))
+    assert s2.size() == 12
+    with pytest.raises(rt.RtError) as e:
+        rt.Scene().load_obj(os.path.join(DATA, "does_not_exist.obj"))
+    assert e.value.code == -5
+
+
+def test_camera_basis():
+    cam = rt.look_at((2.8, 0, 0), (0, 0, 0))
+    assert list(cam.dir) == [-1.0, 0.0, 0.0]
+    assert list(cam.right) == [0.0, 0.0, 1.0]
+    assert [abs(v) for v in cam.down] == [0.0, 1.0, 0.0] and cam.down[1] == -1.0
+
+
+@pytest.mark.parametrize("tag", ["diffuse", "mirror"])
+def test_bmp_writer_bytes(tag, tmp_path):
+    g = golden(f"render_{tag}_64.npz")
+    p = str(tmp_path / "x.bmp")
+    rt.save_bmp(p, g["rgb"])
+    assert eq(np.fromfile(p, np.uint8), g["bmp"])
+
+
+def test_no_cpu_fallback():
+    """Without a GPU a context cannot be created and nothing computes."""
+    if _lib.lib.rt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(rt.RtError) as e:
+        rt.Context(0)
+    assert e.value.code == -2
