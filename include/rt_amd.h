@@ -66,7 +66,13 @@ typedef struct rt_render_params {
     int32_t head_quirk;       /* 1: recurse with the *old* hit object as HEAD does (main.cpp:198,249) */
     int32_t use_photon_map;   /* 0: diffuse hits shade black (no gather)                         */
     int32_t precision;        /* rt_precision of traversal + shading                             */
-    int32_t shadow_rays;      /* extension (not in the reference): one occlusion ray per diffuse primary hit toward light_pos */
+    int32_t shadow_rays;      /* extension (not in the reference): one occlusion ray per primary hit toward light_pos */
+    int32_t count_work;       /* 1: also count inner-node visits and primitive tests (slower instrumented kernel) */
+    /* Row interleave for multi-GPU tiling: with band_rows > 0 the call covers only the bands
+     * b with b % n_parts == part (band b = image rows [b*band_rows, (b+1)*band_rows)); row_begin /
+     * row_end and the output buffers are then in this part's compact row space [0, height/n_parts).
+     * height must be a multiple of band_rows * n_parts.  band_rows = 0: contiguous rows. */
+    int32_t band_rows, n_parts, part;
     double accuracy;          /* main.cpp:614                                                    */
     double photon_dist;       /* PHOTONDIST, Kdtree.cpp:6                                        */
     double light_pos[3];      /* main.cpp:654                                                    */
@@ -78,6 +84,8 @@ typedef struct rt_stats {
     uint64_t secondary_rays;  /* reflection + refraction */
     uint64_t shadow_rays;
     uint64_t gather_queries;  /* KDTree::findKNN calls */
+    uint64_t inner_visits;    /* inner BVH nodes entered (only with count_work) */
+    uint64_t prim_tests;      /* findIntersection calls (only with count_work) */
     double kernel_ms;         /* device time of the call measured with HIP events on the context's stream */
     double trace_kernel_ms;   /* device time of the traversal kernel launches only */
 } rt_stats;

@@ -155,7 +155,8 @@ class Context:
         _chk(lib.rt_trace_closest_dev(self.h, precision, n, d_org, d_dir, d_dist, d_ids), "rt_trace_closest_dev")
 
     def trace_primary(self, cam, params, rows=None, want_t=True):
-        r0, r1 = rows if rows else (0, params.height)
+        part_rows = params.height // params.n_parts if params.band_rows > 0 else params.height
+        r0, r1 = rows if rows else (0, part_rows)
         n = params.width * (r1 - r0)
         ids = np.zeros(n, np.int32)
         t = np.zeros(n) if want_t else None

@@ -27,14 +27,14 @@ class RenderParams(ctypes.Structure):
     _fields_ = [
         ("struct_size", ctypes.c_uint32), ("width", c_i32), ("height", c_i32), ("aadepth", c_i32), ("tracing_depth", c_i32),
         ("photon_num", c_i32), ("photon_use", c_i32), ("head_quirk", c_i32), ("use_photon_map", c_i32), ("precision", c_i32),
-        ("shadow_rays", c_i32), ("accuracy", c_d), ("photon_dist", c_d), ("light_pos", c_d * 3),
+        ("shadow_rays", c_i32), ("count_work", c_i32), ("band_rows", c_i32), ("n_parts", c_i32), ("part", c_i32), ("accuracy", c_d), ("photon_dist", c_d), ("light_pos", c_d * 3),
     ]
 
 
 class Stats(ctypes.Structure):
     _fields_ = [
         ("primary_rays", ctypes.c_uint64), ("secondary_rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64),
-        ("gather_queries", ctypes.c_uint64), ("kernel_ms", c_d), ("trace_kernel_ms", c_d),
+        ("gather_queries", ctypes.c_uint64), ("inner_visits", ctypes.c_uint64), ("prim_tests", ctypes.c_uint64), ("kernel_ms", c_d), ("trace_kernel_ms", c_d),
     ]
 
 

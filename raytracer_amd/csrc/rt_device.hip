@@ -133,7 +133,7 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
     return RT_OK;
 }
 
-template <class R>
+template <class R, bool COUNT>
 int launch_primary(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow)
 {
     int cap = stack_cap(ctx);
@@ -143,7 +143,7 @@ int launch_primary(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, d
     int64_t tiles = (int64_t)((a.width + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
     int blocks = (int)std::min<int64_t>(grid_blocks(ctx, lds), (tiles + rtk::WAVES_PER_BLOCK - 1) / rtk::WAVES_PER_BLOCK);
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((rtk::trace_primary_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a, d_ids, d_t,
+    hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a, d_ids, d_t,
                        d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -155,6 +155,8 @@ int check_params(const rt_render_params* p)
     if (p->struct_size != sizeof(rt_render_params)) return fail(RT_ERR_INVALID, "rt_render_params.struct_size %u != %zu", p->struct_size, sizeof(rt_render_params));
     if (p->width <= 0 || p->height <= 0) return fail(RT_ERR_INVALID, "image size %d x %d", p->width, p->height);
     if (p->precision != RT_F64 && p->precision != RT_F32) return fail(RT_ERR_INVALID, "precision %d", p->precision);
+    if (p->band_rows < 0 || (p->band_rows > 0 && (p->n_parts < 1 || p->part < 0 || p->part >= p->n_parts || p->height % (p->band_rows * p->n_parts) != 0)))
+        return fail(RT_ERR_INVALID, "row interleave band_rows %d n_parts %d part %d does not tile height %d", p->band_rows, p->n_parts, p->part, p->height);
     return RT_OK;
 }
 
@@ -444,7 +446,8 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
     int rc = check_params(p);
     if (rc) return rc;
     if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
-    if (row_begin < 0 || row_end > p->height || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, p->height);
+    int part_rows = p->band_rows > 0 ? p->height / p->n_parts : p->height;
+    if (row_begin < 0 || row_end > part_rows || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, part_rows);
     if (p->aadepth != 1) return fail(RT_ERR_INVALID, "rt_trace_primary handles aadepth 1 only");
     if ((rc = use_device(ctx))) return rc;
     rtk::PrimaryArgs a;
@@ -454,8 +457,12 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
     }
     a.width = p->width; a.height = p->height; a.row_begin = row_begin; a.row_end = row_end;
     a.shadow = p->shadow_rays ? 1 : 0;
+    a.band_rows = p->band_rows; a.n_parts = p->n_parts; a.part = p->part;
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-    rc = p->precision == RT_F64 ? launch_primary<double>(ctx, a, d_ids, d_t, d_shadow_ids) : launch_primary<float>(ctx, a, d_ids, d_t, d_shadow_ids);
+    if (p->count_work)
+        rc = p->precision == RT_F64 ? launch_primary<double, true>(ctx, a, d_ids, d_t, d_shadow_ids) : launch_primary<float, true>(ctx, a, d_ids, d_t, d_shadow_ids);
+    else
+        rc = p->precision == RT_F64 ? launch_primary<double, false>(ctx, a, d_ids, d_t, d_shadow_ids) : launch_primary<float, false>(ctx, a, d_ids, d_t, d_shadow_ids);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (stats) {
@@ -465,6 +472,8 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
         memset(stats, 0, sizeof(*stats));
         stats->primary_rays = (uint64_t)p->width * (uint64_t)(row_end - row_begin);
         stats->shadow_rays = c.shadow;
+        stats->inner_visits = c.inner;
+        stats->prim_tests = c.prims;
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         stats->kernel_ms = ms;
@@ -479,7 +488,8 @@ int rt_trace_primary(rt_context* ctx, const rt_camera* cam, const rt_render_para
     if (!ctx || !ids) return fail(RT_ERR_INVALID, "null argument");
     int rc = check_params(p);
     if (rc) return rc;
-    if (row_begin < 0 || row_end > p->height || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, p->height);
+    int part_rows = p->band_rows > 0 ? p->height / p->n_parts : p->height;
+    if (row_begin < 0 || row_end > part_rows || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, part_rows);
     if ((rc = use_device(ctx))) return rc;
     size_t n = (size_t)p->width * (row_end - row_begin);
     if ((rc = ctx->st_ids.reserve(n * 4))) return rc;

@@ -27,12 +27,16 @@ template <class R> __device__ __forceinline__ bool rt_finite(R v);
 template <> __device__ __forceinline__ bool rt_finite<float>(float v) { return __builtin_isfinite(v); }
 template <> __device__ __forceinline__ bool rt_finite<double>(double v) { return __builtin_isfinite(v); }
 
+struct WorkCount { unsigned long long inner = 0, prims = 0; };
+
 // Leaf: test every primitive in leaf order, accept iff t >= 0 && t < dist (BVH.cpp:135-149).
-template <class R>
-__device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims, uint32_t leaf, const R* o, const R* d, R& dist, int& hit)
+template <class R, bool COUNT>
+__device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims, uint32_t leaf, const R* o, const R* d, R& dist, int& hit,
+                                          WorkCount* wc)
 {
     uint32_t first = leaf & rtf::LEAF_FIRST_MASK;
     uint32_t cnt = (leaf >> rtf::LEAF_COUNT_SHIFT) & 15u;
+    if (COUNT) wc->prims += cnt;
     for (uint32_t k = 0; k < cnt; k++) {
         const rtf::Prim<R>& p = prims[first + k];
         R t = rtm::prim_intersect<R>(p, o, d);
@@ -50,8 +54,9 @@ __device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims
 //     what the pop compares (t0 travels on the stack);
 //   - rays with a non-finite reciprocal direction or origin (axis-parallel rays: 0 * inf = NaN in
 //     the slab test) take the literal path below, which re-runs the full slab test on entry.
-template <class R>
-__device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R& dist, const LaneStack& st, uint32_t* overflow)
+template <class R, bool COUNT = false>
+__device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R& dist, const LaneStack& st, uint32_t* overflow,
+                         WorkCount* wc = nullptr)
 {
     if (d[0] != d[0]) return -1;   // BVH.cpp:110-115
     int hit = -1;
@@ -70,6 +75,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                 while (true) {
                     if (!(cur & rtf::LEAF_BIT)) {
                         const rtf::Node<R>& nd = sv.nodes[cur];
+                        if (COUNT) wc->inner++;
                         R td0 = rtm::slab_finite<R>(nd.lo0, nd.hi0, o, inv, dist);
                         R td1 = rtm::slab_finite<R>(nd.lo1, nd.hi1, o, inv, dist);
                         uint32_t c0 = nd.c0, c1 = nd.c1;
@@ -89,7 +95,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                         if (h0) { cur = c0; continue; }
                         if (h1) { cur = c1; continue; }
                     } else {
-                        test_leaf<R>(sv.prims, cur, o, d, dist, hit);
+                        test_leaf<R, COUNT>(sv.prims, cur, o, d, dist, hit, wc);
                     }
                     bool found = false;
                     while (sp > 0) {
@@ -109,9 +115,10 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                 while (true) {
                     if (have) {
                         if (cur & rtf::LEAF_BIT) {
-                            test_leaf<R>(sv.prims, cur, o, d, dist, hit);
+                            test_leaf<R, COUNT>(sv.prims, cur, o, d, dist, hit, wc);
                         } else {
                             const rtf::Node<R>& nd = sv.nodes[cur];
+                            if (COUNT) wc->inner++;
                             R td0 = rtm::slab_literal<R>(nd.lo0, nd.hi0, o, d, dist);
                             R td1 = rtm::slab_literal<R>(nd.lo1, nd.hi1, o, d, dist);
                             uint32_t first = td0 < td1 ? 0u : 1u;
@@ -171,7 +178,7 @@ __device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap)
 inline size_t stack_lds_bytes(int cap, size_t real_size) { return (size_t)WAVES_PER_BLOCK * cap * WAVE * (sizeof(uint32_t) + real_size); }
 
 // counters[0] = work counter, counters[1] = stack-overflow flag, counters[2] = shadow rays traced
-struct TraceCounters { unsigned long long next; unsigned long long overflow; unsigned long long shadow; unsigned long long pad; };
+struct TraceCounters { unsigned long long next, overflow, shadow, inner, prims, pad[3]; };
 
 // Batch form of BVH::Shoot: rays in SoA doubles (x[n], y[n], z[n]).
 template <class R>
@@ -203,12 +210,13 @@ struct PrimaryArgs {
     double light[3];
     int width, height, row_begin, row_end;
     int shadow;
+    int band_rows, n_parts, part;   // row interleave (band_rows == 0: contiguous)
 };
 
 // Pixel loop front end: camera ray (always generated in double, then rounded to R) + BVH::Shoot
 // with distance 1e9 (main.cpp:812-813); optional shadow ray toward the light.
 // Work unit = 8x8 pixel tile per wave.
-template <class R>
+template <class R, bool COUNT>
 __global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> sv, PrimaryArgs a, int* __restrict__ ids,
                                                               double* __restrict__ t_out, int* __restrict__ shadow_ids,
                                                               TraceCounters* ctr, int cap)
@@ -217,6 +225,7 @@ __global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> 
     LaneStack st = make_stack<R>(lds, cap);
     uint32_t overflow = 0;
     unsigned long long n_shadow = 0;
+    WorkCount wc;
     const int rows = a.row_end - a.row_begin;
     const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
     const unsigned long long n_tiles = (unsigned long long)tiles_x * tiles_y;
@@ -226,12 +235,13 @@ __global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> 
         int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
         int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
         if (x < a.width && yl < rows) {
-            int y = a.row_begin + yl;
+            int yc = a.row_begin + yl;   // row in this call's (compact) row space
+            int y = a.band_rows > 0 ? ((yc / a.band_rows) * a.n_parts + a.part) * a.band_rows + yc % a.band_rows : yc;
             rtm::D3 dd = rtm::camera_ray_dir(a.cam_dir, a.cam_right, a.cam_down, a.width, a.height, 1, x, y, 0);
             R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
             R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
             R dist = R(1e9);
-            int id = trace_ray<R>(sv, o, d, dist, st, &overflow);
+            int id = trace_ray<R, COUNT>(sv, o, d, dist, st, &overflow, &wc);
             long long px = (long long)yl * a.width + x;
             ids[px] = id;
             if (t_out) t_out[px] = (double)dist;
@@ -249,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> 
                     R o2[3] = {(R)so.x, (R)so.y, (R)so.z};
                     R d2[3] = {(R)L.x, (R)L.y, (R)L.z};
                     R range = (R)(len - 1e-4);
-                    sid = trace_ray<R>(sv, o2, d2, range, st, &overflow);
+                    sid = trace_ray<R, COUNT>(sv, o2, d2, range, st, &overflow, &wc);
                     n_shadow++;
                 }
                 if (shadow_ids) shadow_ids[px] = sid;
@@ -261,6 +271,10 @@ __global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> 
         // one atomic per wave
         for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);
         if (st.lane == 0 && n_shadow) atomicAdd(&ctr->shadow, n_shadow);
+    }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { wc.inner += __shfl_down(wc.inner, off); wc.prims += __shfl_down(wc.prims, off); }
+        if (st.lane == 0) { atomicAdd(&ctr->inner, wc.inner); atomicAdd(&ctr->prims, wc.prims); }
     }
 }
 
