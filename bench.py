@@ -15,7 +15,6 @@ Rank 0 prints ONE JSON line.  metric = Mrays/s over all closest-hit queries (pri
 """
 import argparse
 import json
-import math
 import os
 import sys
 import time
@@ -28,16 +27,7 @@ sys.path.insert(0, ROOT)
 DATA = os.path.join(ROOT, "tests", "golden", "data")
 GOLD = os.path.join(ROOT, "tests", "golden")
 CAM = np.array([2.8, 0, 0, 0, 0, 0.0])
-BAND = 8
 HBM_PEAK_GBS = 8000.0
-
-
-def frame_size(n_gpus):
-    s = math.sqrt(n_gpus)
-    w = int(round(1920 * s / 8)) * 8
-    q = BAND * n_gpus
-    h = int(round(1080 * s / q)) * q
-    return w, h
 
 
 def main():
@@ -61,6 +51,8 @@ def main():
     import torch.distributed as dist
 
     import raytracer_amd as rt
+    from raytracer_amd import tiling
+    BAND = tiling.BAND
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -76,8 +68,8 @@ def main():
     ctx.upload(scene)
     cam = rt.look_at(CAM[:3], CAM[3:])
 
-    w, h = frame_size(world)
-    part_rows = h // world
+    w, h = tiling.frame_size(world)
+    part_rows = tiling.part_rows(h, world)
     prec = rt.RT_F64 if args.precision == "f64" else rt.RT_F32
 
     def make_params(precision, count_work=0):
@@ -87,7 +79,7 @@ def main():
     params = make_params(prec)
     # per-rank hit buffers in HBM: [0] primary ids, [1] shadow ids
     buf = torch.empty((2, part_rows, w), dtype=torch.int32, device=dev)
-    gathered = [torch.empty_like(buf) for _ in range(world)] if (world > 1 and rank == 0) else None
+    recv = [torch.empty_like(buf) for _ in range(world)] if (world > 1 and rank == 0) else None
     torch.cuda.synchronize()
 
     kernel_ms = []
@@ -95,7 +87,7 @@ def main():
     def step(p, record=False):
         st = ctx.trace_primary_dev(cam, p, (0, part_rows), buf[0].data_ptr(), None, buf[1].data_ptr(), stats=True)  # synchronises the context stream
         if world > 1:
-            dist.gather(buf, gathered, dst=0)   # RCCL: each rank sends its bands straight to rank 0
+            tiling.gather_to_rank0(buf, world, rank, dist, recv)   # RCCL: each rank sends its bands straight to rank 0
         if record:
             kernel_ms.append(st.trace_kernel_ms)
         return st
@@ -188,7 +180,7 @@ def main():
         "config": {
             "workload": f"{args.mesh} + Cornell box ({scene.size()} triangles, BVH depth {scene.bvh_depth()}), {w}x{h}, primary + 1 shadow ray per hit",
             "rays_per_step": int(rays_per_step),
-            "parallelism": f"rows in bands of {BAND} over {world} GPU(s), scene replicated, RCCL gather to rank 0" if world > 1 else "1 GPU",
+            "parallelism": f"rows in bands of {tiling.BAND} over {world} GPU(s), scene replicated, RCCL gather to rank 0" if world > 1 else "1 GPU",
         },
         "roofline": {
             "bound": "hbm",

@@ -137,6 +137,16 @@ int rt_scene_build_bvh(rt_scene* s);
 int rt_scene_bvh_dump(const rt_scene* s, int32_t* rec, int64_t* n_rec, double* boxes, int64_t* n_boxes);
 int rt_scene_bvh_depth(const rt_scene* s);
 
+/* Photon emission, main.cpp:396-598 + the loop of main.cpp:697-718, on the host (it is RNG-order
+ * dependent): n_emit photons from light_pos, one thread, std::mt19937 seeded with `seed` (the
+ * reference seeds from std::random_device).  bounce = BOUNCE (main.cpp:25).  Needs the BVH.  The
+ * stored photons stay in the scene: which = 0 surface map (main.cpp:44), 1 volume map (main.cpp:45);
+ * rt_scene_photons_get copies n x 9 doubles (position, power rgb, direction; Photon.h:7-28). */
+int rt_scene_emit_photons(rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy);
+int64_t rt_scene_photon_count(const rt_scene* s, int which);
+int rt_scene_photons_get(const rt_scene* s, int which, double* photons);
+void rt_scene_photons_clear(rt_scene* s);
+
 /* ---- device: scene + traversal ----------------------------------------------------------- */
 /* copy the flattened scene (64 B-aligned node / primitive / material arrays, f64 and f32 forms) to HBM */
 int rt_scene_upload(rt_context* ctx, const rt_scene* s);

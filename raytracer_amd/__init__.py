@@ -104,6 +104,23 @@ class Scene:
     def build_bvh(self):
         _chk(lib.rt_scene_build_bvh(self.h), "rt_scene_build_bvh")
 
+    def emit_photons(self, n_emit, light_pos=(0.1, 0.2, 0.0), seed=12345, bounce=5, accuracy=1e-6):
+        """Host-side photon emission (main.cpp:697-718 + photonEmission); returns the surface photon count."""
+        _chk(lib.rt_scene_emit_photons(self.h, n_emit, _dp(_f64(light_pos)), seed, bounce, accuracy), "rt_scene_emit_photons")
+        return self.photon_count(0)
+
+    def photon_count(self, which=0):
+        return lib.rt_scene_photon_count(self.h, which)
+
+    def photons_get(self, which=0):
+        out = np.zeros((self.photon_count(which), 9))
+        if len(out):
+            _chk(lib.rt_scene_photons_get(self.h, which, _dp(out)), "rt_scene_photons_get")
+        return out
+
+    def photons_clear(self):
+        lib.rt_scene_photons_clear(self.h)
+
     def bvh_depth(self):
         return lib.rt_scene_bvh_depth(self.h)
 
@@ -172,6 +189,58 @@ class Context:
         _chk(lib.rt_trace_primary_dev(self.h, ctypes.byref(cam), ctypes.byref(params), rows[0], rows[1], d_ids, d_t, d_shadow,
                                       ctypes.byref(st) if stats else None), "rt_trace_primary_dev")
         return st
+
+
+def _ctx_photons_upload(self, photons, which=0):
+    photons = _f64(photons)
+    assert photons.ndim == 2 and photons.shape[1] == 9
+    _chk(lib.rt_photons_upload(self.h, which, photons.shape[0], _dp(photons)), "rt_photons_upload")
+
+
+def _ctx_knn_radius(self, k, centers, max_dist=0.28, which=0):
+    centers = _f64(centers)
+    n = centers.shape[0]
+    cnt = np.zeros(n, np.int32)
+    r2 = np.zeros(n)
+    _chk(lib.rt_knn_radius(self.h, which, k, max_dist, n, _dp(centers), cnt.ctypes.data_as(_lib.P(_lib.c_i32)), _dp(r2)), "rt_knn_radius")
+    return cnt, r2
+
+
+def _ctx_knn_estimate(self, params, pos, normal, color):
+    pos = _f64(pos); normal = _f64(normal); color = _f64(color)
+    n = pos.shape[0]
+    rgb = np.zeros((n, 3))
+    cnt = np.zeros(n, np.int32)
+    _chk(lib.rt_knn_estimate(self.h, ctypes.byref(params), n, _dp(pos), _dp(normal), _dp(color), _dp(rgb),
+                             cnt.ctypes.data_as(_lib.P(_lib.c_i32))), "rt_knn_estimate")
+    return rgb, cnt
+
+
+def _ctx_render(self, cam, params, rows=None):
+    """Full pixel path for a row block: returns (rgb float64 [rows, w, 3], bgr8 uint8 [rows, w, 3], Stats)."""
+    part_rows = params.height // params.n_parts if params.band_rows > 0 else params.height
+    r0, r1 = rows if rows else (0, part_rows)
+    n = params.width * (r1 - r0)
+    rgb = np.zeros((r1 - r0, params.width, 3))
+    bgr = np.zeros((r1 - r0, params.width, 3), np.uint8)
+    st = Stats()
+    _chk(lib.rt_render_rows(self.h, ctypes.byref(cam), ctypes.byref(params), r0, r1, _dp(rgb), bgr.ctypes.data_as(_lib.P(_lib.c_u8)),
+                            ctypes.byref(st)), "rt_render_rows")
+    return rgb, bgr, st
+
+
+def _ctx_render_dev(self, cam, params, rows, d_rgb, d_bgr8, stats=True):
+    st = Stats()
+    _chk(lib.rt_render_rows_dev(self.h, ctypes.byref(cam), ctypes.byref(params), rows[0], rows[1], d_rgb, d_bgr8,
+                                ctypes.byref(st) if stats else None), "rt_render_rows_dev")
+    return st
+
+
+Context.photons_upload = _ctx_photons_upload
+Context.knn_radius = _ctx_knn_radius
+Context.knn_estimate = _ctx_knn_estimate
+Context.render = _ctx_render
+Context.render_dev = _ctx_render_dev
 
 
 def save_bmp(path, rgb, dpi=72):

@@ -67,6 +67,10 @@ PROTOTYPES = {
     "rt_scene_build_bvh": (c_i, [vp]),
     "rt_scene_bvh_dump": (c_i, [vp, P(c_i32), P(c_i64), P(c_d), P(c_i64)]),
     "rt_scene_bvh_depth": (c_i, [vp]),
+    "rt_scene_emit_photons": (c_i, [vp, c_i64, P(c_d), ctypes.c_uint32, c_i, c_d]),
+    "rt_scene_photon_count": (c_i64, [vp, c_i]),
+    "rt_scene_photons_get": (c_i, [vp, c_i, P(c_d)]),
+    "rt_scene_photons_clear": (None, [vp]),
     "rt_scene_upload": (c_i, [vp, vp]),
     "rt_trace_closest": (c_i, [vp, c_i, c_i64, P(c_d), P(c_d), P(c_d), P(c_i32)]),
     "rt_trace_closest_dev": (c_i, [vp, c_i, c_i64, vp, vp, vp, vp]),

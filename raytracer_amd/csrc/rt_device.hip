@@ -9,10 +9,13 @@
 #include <vector>
 
 #include "../../include/rt_amd.h"
+#include "host_photon.h"
 #include "host_scene.h"
 #include "rt_flat.h"
+#include "rt_gather.hip.h"
 #include "rt_kernels.hip.h"
 #include "rt_math.h"
+#include "rt_render.hip.h"
 
 namespace {
 
@@ -68,6 +71,7 @@ int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
 
 struct rt_scene {
     rth::Scene s;
+    std::vector<rth::PhotonRec> photons[2];   // 0 surface, 1 volume
 };
 
 struct rt_context {
@@ -82,7 +86,12 @@ struct rt_context {
     int depth = 0;
     int n_objects = 0;
     bool has_scene = false;
-    DevBuf counters;          // rtk::TraceCounters
+    DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
+    // photon maps in HBM (0 surface, 1 volume)
+    DevBuf ph_pos[2], ph_aux[2], ph_axis[2];
+    rtg::PhotonMapView pm[2] = {};
+    // render queues
+    DevBuf hits_a, hits_b, gq, acc;
     // staging for the host-buffer convenience entry points
     DevBuf st_org, st_dir, st_dist, st_ids, st_aux;
 };
@@ -195,7 +204,7 @@ int rt_context_create(int device, rt_context** out)
     }
     for (auto& ev : ctx->ev)
         if (hipEventCreate(&ev) != hipSuccess) { delete ctx; return fail(RT_ERR_HIP, "hipEventCreate failed"); }
-    int rc = ctx->counters.reserve(256);
+    int rc = ctx->counters.reserve(1024);
     if (rc) { delete ctx; return rc; }
     *out = ctx;
     return RT_OK;
@@ -207,7 +216,9 @@ void rt_context_destroy(rt_context* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
-                      &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux})
+                      &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
+                      &ctx->hits_b, &ctx->gq, &ctx->acc, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
+                      &ctx->ph_axis[1]})
         b->release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -348,6 +359,31 @@ int rt_scene_bvh_dump(const rt_scene* s, int32_t* rec, int64_t* n_rec, double* b
     return RT_OK;
 }
 int rt_scene_bvh_depth(const rt_scene* s) { return (s && s->s.bvh.built) ? s->s.bvh.depth : -1; }
+
+int rt_scene_emit_photons(rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy)
+{
+    if (!s || !light_pos || n_emit < 0) return fail(RT_ERR_INVALID, "bad argument");
+    if (!s->s.bvh.built) return fail(RT_ERR_STATE, "rt_scene_build_bvh has not been called");
+    rth::EmitParams ep;
+    ep.bounce = bounce;
+    ep.accuracy = accuracy;
+    rth::emit_photons(s->s, n_emit, light_pos, seed, ep, s->photons[0], s->photons[1]);
+    return RT_OK;
+}
+int64_t rt_scene_photon_count(const rt_scene* s, int which) { return (s && (which == 0 || which == 1)) ? (int64_t)s->photons[which].size() : -1; }
+int rt_scene_photons_get(const rt_scene* s, int which, double* photons)
+{
+    if (!s || !photons || (which != 0 && which != 1)) return fail(RT_ERR_INVALID, "bad argument");
+    static_assert(sizeof(rth::PhotonRec) == 9 * sizeof(double), "PhotonRec is 9 doubles");
+    memcpy(photons, s->photons[which].data(), s->photons[which].size() * sizeof(rth::PhotonRec));
+    return RT_OK;
+}
+void rt_scene_photons_clear(rt_scene* s)
+{
+    if (!s) return;
+    s->photons[0].clear();
+    s->photons[1].clear();
+}
 
 // ---------------------------------------------------------------- device scene
 int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
@@ -507,12 +543,230 @@ int rt_trace_primary(rt_context* ctx, const rt_camera* cam, const rt_render_para
     return RT_OK;
 }
 
-// ---------------------------------------------------------------- not built yet
-int rt_photons_upload(rt_context*, int, int64_t, const double*) { return fail(RT_ERR_STATE, "photon map path not built in this library version"); }
-int rt_knn_radius(rt_context*, int, int, double, int64_t, const double*, int32_t*, double*) { return fail(RT_ERR_STATE, "photon map path not built in this library version"); }
-int rt_knn_estimate(rt_context*, const rt_render_params*, int64_t, const double*, const double*, const double*, double*, int32_t*) { return fail(RT_ERR_STATE, "photon map path not built in this library version"); }
-int rt_render_rows_dev(rt_context*, const rt_camera*, const rt_render_params*, int, int, double*, uint8_t*, rt_stats*) { return fail(RT_ERR_STATE, "render path not built in this library version"); }
-int rt_render_rows(rt_context*, const rt_camera*, const rt_render_params*, int, int, double*, uint8_t*, rt_stats*) { return fail(RT_ERR_STATE, "render path not built in this library version"); }
+// ---------------------------------------------------------------- photon map
+int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photons)
+{
+    if (!ctx || (which != 0 && which != 1) || n < 0 || (n > 0 && !photons)) return fail(RT_ERR_INVALID, "bad argument");
+    if (n >= (1ll << 31)) return fail(RT_ERR_LIMIT, "photon count %lld exceeds 2^31", (long long)n);
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    rth::FlatPhotonMap fm;
+    rth::build_photon_map(photons, n, fm);
+    if ((rc = upload(ctx->ph_pos[which], fm.pos, ctx->stream))) return rc;
+    if ((rc = upload(ctx->ph_aux[which], fm.aux, ctx->stream))) return rc;
+    if ((rc = upload(ctx->ph_axis[which], fm.axis, ctx->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->pm[which].pos = (const float*)ctx->ph_pos[which].p;
+    ctx->pm[which].aux = (const float*)ctx->ph_aux[which].p;
+    ctx->pm[which].axis = (const uint8_t*)ctx->ph_axis[which].p;
+    ctx->pm[which].n = n;
+    return RT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int knn_launch(rt_context* ctx, int which, int k, double max_dist, int photon_num, int64_t n, const double* pos, const double* nrm, const double* col,
+               int32_t* counts, double* r2, double* rgb)
+{
+    if (k < 1 || k > rtg::MAX_K) return fail(RT_ERR_LIMIT, "k = %d outside [1, %d]", k, rtg::MAX_K);
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    size_t b3 = (size_t)n * 3 * sizeof(double);
+    if ((rc = ctx->st_org.reserve(b3))) return rc;
+    if ((rc = ctx->st_dir.reserve(b3 * 3))) return rc;          // normals | colours | rgb out
+    if ((rc = ctx->st_dist.reserve((size_t)n * 8))) return rc;
+    if ((rc = ctx->st_ids.reserve((size_t)n * 4))) return rc;
+    double* d_pos = (double*)ctx->st_org.p;
+    double* d_nrm = (double*)ctx->st_dir.p;
+    double* d_col = d_nrm + (size_t)n * 3;
+    double* d_rgb = d_col + (size_t)n * 3;
+    HIP_TRY(hipMemcpyAsync(d_pos, pos, b3, hipMemcpyHostToDevice, ctx->stream));
+    if (nrm) HIP_TRY(hipMemcpyAsync(d_nrm, nrm, b3, hipMemcpyHostToDevice, ctx->stream));
+    if (col) HIP_TRY(hipMemcpyAsync(d_col, col, b3, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    rtg::GatherParams gp;
+    gp.k = k;
+    gp.r2 = (float)(max_dist * max_dist);
+    gp.norm = (double)(photon_num / 16) * 3.1415926;            // PHOTONMUM/16*PI, integer division first (main.cpp:293)
+    int blocks = (int)std::min<int64_t>(n, (int64_t)ctx->num_cus * 8);
+    hipLaunchKernelGGL(rtg::knn_batch_kernel, dim3(blocks), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[which], (long long)n, d_pos,
+                       nrm ? d_nrm : nullptr, col ? d_col : nullptr, gp, (int*)ctx->st_ids.p, (double*)ctx->st_dist.p, rgb ? d_rgb : nullptr,
+                       (unsigned long long*)ctx->counters.p);
+    HIP_TRY(hipGetLastError());
+    if (counts) HIP_TRY(hipMemcpyAsync(counts, ctx->st_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (r2) HIP_TRY(hipMemcpyAsync(r2, ctx->st_dist.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (rgb) HIP_TRY(hipMemcpyAsync(rgb, d_rgb, b3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rt_knn_radius(rt_context* ctx, int which, int k, double max_dist, int64_t n, const double* centers, int32_t* counts, double* r2)
+{
+    if (!ctx || !centers || (which != 0 && which != 1) || n < 0) return fail(RT_ERR_INVALID, "bad argument");
+    if (n == 0) return RT_OK;
+    return knn_launch(ctx, which, k, max_dist, 16, n, centers, nullptr, nullptr, counts, r2, nullptr);
+}
+
+int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal, const double* color,
+                    double* rgb, int32_t* counts)
+{
+    if (!ctx || !pos || !normal || !color || !rgb || n < 0) return fail(RT_ERR_INVALID, "bad argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n == 0) return RT_OK;
+    return knn_launch(ctx, 0, p->photon_use, p->photon_dist, p->photon_num, n, pos, normal, color, counts, nullptr, rgb);
+}
+
+// ---------------------------------------------------------------- full pixel path
+}  // extern "C"
+
+namespace {
+
+template <class R>
+int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, double* d_acc, rtr::RenderCounters* host_ctr)
+{
+    const int rows = a.row_end - a.row_begin;
+    const unsigned long long samples = (unsigned long long)a.width * rows * a.aadepth;
+    const int levels = std::min(p->tracing_depth, rtr::MAX_LEVELS);
+    // worst case: every hit of a level spawns two (reflection + refraction)
+    const unsigned long long cap_hits = samples << std::max(0, std::min(levels - 1, 3));
+    const unsigned long long cap_gq = cap_hits;
+    int rc;
+    if ((rc = ctx->hits_a.reserve(cap_hits * sizeof(rtr::HitRec)))) return rc;
+    if ((rc = ctx->hits_b.reserve(cap_hits * sizeof(rtr::HitRec)))) return rc;
+    if ((rc = ctx->gq.reserve(cap_gq * sizeof(rtg::GatherRec)))) return rc;
+    int cap = stack_cap(ctx);
+    size_t lds = rtk::stack_lds_bytes(cap, sizeof(R));
+    if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
+    rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)a.width * rows * 3 * sizeof(double), ctx->stream));
+    int blocks = grid_blocks(ctx, lds);
+    rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
+    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    hipLaunchKernelGGL((rtr::render_primary_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a,
+                       (rtr::HitRec*)ctx->hits_a.p, cap_hits, ctr, cap);
+    HIP_TRY(hipGetLastError());
+    rtr::HitRec* qin = (rtr::HitRec*)ctx->hits_a.p;
+    rtr::HitRec* qout = (rtr::HitRec*)ctx->hits_b.p;
+    for (int level = 1; level <= levels; level++) {
+        hipLaunchKernelGGL((rtr::shade_level_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), sd, a, level,
+                           level == levels ? 1 : 0, qin, qout, cap_hits, (rtg::GatherRec*)ctx->gq.p, cap_gq, ctr, cap);
+        HIP_TRY(hipGetLastError());
+        std::swap(qin, qout);
+    }
+    HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    if (p->use_photon_map && ctx->pm[0].n > 0) {
+        rtg::GatherParams gp;
+        gp.k = p->photon_use;
+        gp.r2 = (float)(p->photon_dist * p->photon_dist);
+        gp.norm = (double)(p->photon_num / 16) * 3.1415926;
+        hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], (const rtg::GatherRec*)ctx->gq.p,
+                           &ctr->n_gather, &ctr->next_gather, gp, d_acc);
+        HIP_TRY(hipGetLastError());
+    }
+    if (host_ctr) HIP_TRY(hipMemcpyAsync(host_ctr, ctr, sizeof(*host_ctr), hipMemcpyDeviceToHost, ctx->stream));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end, double* d_rgb,
+                       uint8_t* d_bgr8, rt_stats* stats)
+{
+    if (!ctx || !cam) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
+    int part_rows = p->band_rows > 0 ? p->height / p->n_parts : p->height;
+    if (row_begin < 0 || row_end > part_rows || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, part_rows);
+    if (p->aadepth < 1 || p->aadepth > 16) return fail(RT_ERR_INVALID, "aadepth %d", p->aadepth);
+    if (p->tracing_depth < 1 || p->tracing_depth > rtr::MAX_LEVELS) return fail(RT_ERR_INVALID, "tracing_depth %d outside [1,%d]", p->tracing_depth, rtr::MAX_LEVELS);
+    if (p->use_photon_map && (p->photon_use < 1 || p->photon_use > rtg::MAX_K)) return fail(RT_ERR_LIMIT, "photon_use %d outside [1,%d]", p->photon_use, rtg::MAX_K);
+    if ((rc = use_device(ctx))) return rc;
+
+    rtr::RenderArgs a;
+    for (int i = 0; i < 3; i++) { a.cam_pos[i] = cam->pos[i]; a.cam_dir[i] = cam->dir[i]; a.cam_right[i] = cam->right[i]; a.cam_down[i] = cam->down[i]; }
+    a.width = p->width; a.height = p->height;
+    a.band_rows = p->band_rows; a.n_parts = p->n_parts; a.part = p->part;
+    a.aadepth = p->aadepth;
+    a.accuracy = p->accuracy;
+    a.head_quirk = p->head_quirk; a.use_photon_map = p->use_photon_map;
+
+    // row chunks bound the queue memory: at most ~4M distinct camera rays per chunk
+    const long long max_samples = 4ll << 20;
+    int chunk_rows = (int)std::max<long long>(8, (max_samples / ((long long)p->width * p->aadepth)) / 8 * 8);
+    std::vector<rtr::RenderCounters> hc((size_t)((row_end - row_begin + chunk_rows - 1) / chunk_rows));
+    rt_stats total;
+    memset(&total, 0, sizeof total);
+    HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    size_t ci = 0;
+    for (int r0 = row_begin; r0 < row_end; r0 += chunk_rows, ci++) {
+        int r1 = std::min(row_end, r0 + chunk_rows);
+        size_t npx = (size_t)p->width * (r1 - r0);
+        size_t off = (size_t)p->width * (r0 - row_begin);
+        double* acc;
+        if (d_rgb) {
+            acc = d_rgb + off * 3;
+        } else {
+            if ((rc = ctx->acc.reserve(npx * 3 * sizeof(double)))) return rc;
+            acc = (double*)ctx->acc.p;
+        }
+        a.row_begin = r0; a.row_end = r1;
+        rc = p->precision == RT_F64 ? render_block<double>(ctx, a, p, acc, stats ? &hc[ci] : nullptr) : render_block<float>(ctx, a, p, acc, stats ? &hc[ci] : nullptr);
+        if (rc) return rc;
+        int threads = 256;
+        hipLaunchKernelGGL(rtr::resolve_kernel, dim3((unsigned)((npx + threads - 1) / threads)), dim3(threads), 0, ctx->stream, (long long)npx, p->aadepth,
+                           acc, d_rgb ? acc : nullptr, d_bgr8 ? d_bgr8 + off * 3 : nullptr);
+        HIP_TRY(hipGetLastError());
+        total.primary_rays += (uint64_t)npx * p->aadepth;
+    }
+    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (stats) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < ci; i++) {
+            if (hc[i].overflow_stack) return fail(RT_ERR_LIMIT, "traversal stack overflow");
+            if (hc[i].overflow_queue) return fail(RT_ERR_LIMIT, "bounce/gather queue overflow");
+            total.secondary_rays += hc[i].secondary_rays;
+            total.gather_queries += hc[i].n_gather;
+        }
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        total.kernel_ms = ms;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));   // trace + shade kernels of the last chunk
+        total.trace_kernel_ms = ms;
+        *stats = total;
+    }
+    return RT_OK;
+}
+
+int rt_render_rows(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end, double* rgb, uint8_t* bgr8,
+                   rt_stats* stats)
+{
+    if (!ctx || !cam || (!rgb && !bgr8)) return fail(RT_ERR_INVALID, "null argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    int part_rows = p->band_rows > 0 ? p->height / p->n_parts : p->height;
+    if (row_begin < 0 || row_end > part_rows || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, part_rows);
+    if ((rc = use_device(ctx))) return rc;
+    size_t npx = (size_t)p->width * (row_end - row_begin);
+    if ((rc = ctx->st_org.reserve(npx * 3 * sizeof(double)))) return rc;
+    if ((rc = ctx->st_aux.reserve(npx * 3))) return rc;
+    rt_stats local;
+    rc = rt_render_rows_dev(ctx, cam, p, row_begin, row_end, (double*)ctx->st_org.p, (uint8_t*)ctx->st_aux.p, &local);
+    if (rc) return rc;
+    if (rgb) HIP_TRY(hipMemcpyAsync(rgb, ctx->st_org.p, npx * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (bgr8) HIP_TRY(hipMemcpyAsync(bgr8, ctx->st_aux.p, npx * 3, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (stats) *stats = local;
+    return RT_OK;
+}
 
 // ---------------------------------------------------------------- host I/O
 int rt_save_bmp(const char* path, int w, int h, int dpi, const double* rgb)

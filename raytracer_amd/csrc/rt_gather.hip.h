@@ -1,0 +1,309 @@
+// K4: bounded k-NN photon gather + radiance estimate (KDTree::findKNN, Kdtree.cpp:73-158, and the
+// estimate of main.cpp:260-295), one query per wave64.
+//
+// The reference walks a pointer kd-tree keeping a max-heap of k photon pointers.  Here the tree is
+// implicit over one in-order array (see FlatPhotonMap); the whole wave walks it together:
+//   - inner node: the pivot photon is tested, the near side is entered, the far side is pushed
+//     with its squared plane distance and skipped on pop once that exceeds the current bound
+//     (same pruning as Kdtree.cpp:121-132, with the up-to-date bound);
+//   - leaf (<= 64 photons): one photon per lane, coalesced; photons with d2 < bound are appended
+//     to a candidate buffer in LDS through a ballot prefix;
+//   - when the buffer is nearly full, a wave-wide radix select finds the k-th smallest d2, keeps
+//     exactly the k nearest candidates and tightens the bound to that distance.
+// The result is the exact k-nearest set within the radius (ties at the k-th distance arbitrary,
+// as with the reference's heap); only max d2 and the weighted sum leave the kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtg {
+
+constexpr int WAVE = 64;
+constexpr int CAP = 2048;        // candidate buffer entries per wave
+constexpr int MAX_K = CAP - 2 * WAVE;
+constexpr int STACK = 48;        // > log2(2^31 / 64) levels
+
+struct PhotonMapView {
+    const float* pos;            // 3 per photon, tree order
+    const float* aux;            // 6 per photon: power rgb, dir xyz
+    const uint8_t* axis;
+    long long n;
+};
+
+// one gather request = one diffuse hit
+struct GatherRec {
+    double pos[3];
+    double normal[3];
+    double color[3];
+    double weight;               // path throughput the estimate is scaled by
+    uint32_t pixel;
+    uint32_t pad;
+};
+
+struct WaveLds {
+    float key[CAP];
+    uint32_t idx[CAP];
+    uint32_t hist[256];
+    int s_lo[STACK], s_hi[STACK];
+    float s_d2[STACK];
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ unsigned prefix_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// k-th smallest (1-based) of key[0..count): wave-wide MSB-first radix select on the float bits
+// (all keys are non-negative, so the unsigned bit pattern orders like the value).  Afterwards the
+// buffer holds exactly the k smallest entries.  Returns the k-th key.
+__device__ float select_k(WaveLds& L, int& count, int k)
+{
+    const int lane = lane_id();
+    uint32_t prefix = 0, pmask = 0;
+    int want = k;
+    for (int pass = 3; pass >= 0; pass--) {
+        for (int b = lane; b < 256; b += WAVE) L.hist[b] = 0;
+        __builtin_amdgcn_wave_barrier();
+        for (int j = lane; j < count; j += WAVE) {
+            uint32_t u = __float_as_uint(L.key[j]);
+            if ((u & pmask) == prefix) atomicAdd(&L.hist[(u >> (8 * pass)) & 255u], 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // lane l owns bins 4l .. 4l+3
+        uint32_t h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2], h3 = L.hist[4 * lane + 3];
+        uint32_t s = h0 + h1 + h2 + h3;
+        uint32_t incl = s;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        uint32_t excl = incl - s;
+        bool mine = (uint32_t)want > excl && (uint32_t)want <= incl;   // exactly one lane
+        uint32_t bin = 0, below = 0;
+        if (mine) {
+            uint32_t w = (uint32_t)want - excl;
+            if (w <= h0) { bin = 0; below = excl; }
+            else if (w <= h0 + h1) { bin = 1; below = excl + h0; }
+            else if (w <= h0 + h1 + h2) { bin = 2; below = excl + h0 + h1; }
+            else { bin = 3; below = excl + h0 + h1 + h2; }
+            bin += 4 * lane;
+        }
+        unsigned long long who = __ballot(mine);
+        int src = __builtin_ctzll(who);
+        bin = __shfl(bin, src);
+        below = __shfl(below, src);
+        want -= (int)below;
+        prefix |= bin << (8 * pass);
+        pmask |= 255u << (8 * pass);
+        __builtin_amdgcn_wave_barrier();
+    }
+    const uint32_t T = prefix;     // bit pattern of the k-th smallest key; `want` = how many == T to keep
+    // stable in-place compaction, one 64-entry chunk at a time (outputs never pass the read cursor)
+    int out = 0, eq_taken = 0;
+    for (int base = 0; base < count; base += WAVE) {
+        int j = base + lane;
+        bool valid = j < count;
+        uint32_t u = valid ? __float_as_uint(L.key[j]) : 0xFFFFFFFFu;
+        uint32_t id = valid ? L.idx[j] : 0u;
+        bool less = valid && u < T;
+        bool eq = valid && u == T;
+        unsigned long long meq = __ballot(eq);
+        bool keep = less || (eq && (eq_taken + (int)prefix_rank(meq)) < want);
+        unsigned long long mk = __ballot(keep);
+        __builtin_amdgcn_wave_barrier();
+        if (keep) {
+            int p = out + (int)prefix_rank(mk);
+            L.key[p] = __uint_as_float(u);
+            L.idx[p] = id;
+        }
+        out += __builtin_popcountll(mk);
+        eq_taken += __builtin_popcountll(meq);
+        __builtin_amdgcn_wave_barrier();
+    }
+    count = out;
+    return __uint_as_float(T);
+}
+
+__device__ __forceinline__ void append(WaveLds& L, int& count, bool take, float d2, uint32_t id)
+{
+    unsigned long long m = __ballot(take);
+    if (take) {
+        int p = count + (int)prefix_rank(m);
+        L.key[p] = d2;
+        L.idx[p] = id;
+    }
+    count += __builtin_popcountll(m);
+}
+
+// Walk the implicit tree for one query held identically by all lanes.  On return L.key/L.idx[0..count)
+// is the k-nearest set within sqrt(r2).
+__device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float qy, float qz, int k, float r2, int& count)
+{
+    const int lane = lane_id();
+    count = 0;
+    if (pm.n <= 0) return;
+    float bound = r2;            // candidates need d2 < bound (Kdtree.cpp:77,82: strict)
+    const float q[3] = {qx, qy, qz};
+    int sp = 0;
+    int lo = 0, hi = (int)pm.n;
+    float dfar = 0.f;
+    bool have = true;
+    while (true) {
+        if (!have) {
+            if (sp == 0) break;
+            sp--;
+            lo = L.s_lo[sp]; hi = L.s_hi[sp]; dfar = L.s_d2[sp];
+            if (dfar > bound) continue;          // Kdtree.cpp:123-125: far side only if delta^2 <= bound
+        }
+        have = false;
+        while (hi - lo > WAVE) {
+            int mid = lo + (hi - lo) / 2;
+            int ax = pm.axis[mid];
+            float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
+            float dx = qx - px, dy = qy - py, dz = qz - pz;
+            float d2 = dx * dx + dy * dy + dz * dz;
+            append(L, count, lane == 0 && d2 < bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119)
+            float split = ax == 0 ? px : (ax == 1 ? py : pz);
+            float delta = q[ax] - split;
+            int nlo, nhi, flo, fhi;
+            if (delta < 0.f) { nlo = lo; nhi = mid; flo = mid + 1; fhi = hi; }      // Kdtree.cpp:121
+            else { nlo = mid + 1; nhi = hi; flo = lo; fhi = mid; }
+            float dd = delta * delta;
+            if (fhi > flo && dd <= bound && sp < STACK) {
+                if (lane == 0) { L.s_lo[sp] = flo; L.s_hi[sp] = fhi; L.s_d2[sp] = dd; }
+                sp++;
+            }
+            lo = nlo; hi = nhi;
+        }
+        {   // leaf: one photon per lane
+            int i = lo + lane;
+            bool valid = i < hi;
+            float d2 = 3.0e38f;
+            if (valid) {
+                float dx = qx - pm.pos[3 * (size_t)i], dy = qy - pm.pos[3 * (size_t)i + 1], dz = qz - pm.pos[3 * (size_t)i + 2];
+                d2 = dx * dx + dy * dy + dz * dz;
+            }
+            append(L, count, valid && d2 < bound, d2, (uint32_t)i);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (count > CAP - 2 * WAVE) bound = select_k(L, count, k);
+    }
+    if (count > k) select_k(L, count, k);
+}
+
+struct GatherParams {
+    int k;
+    float r2;
+    double norm;      // PHOTONMUM / 16 * PI  (integer division first, main.cpp:293)
+};
+
+// reduce a double over the wave (all lanes get lane 0's total after the final shuffle)
+__device__ __forceinline__ double wave_sum(double v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return __shfl(v, 0);
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off));
+    return __shfl(v, 0);
+}
+
+// Radiance estimate over the gathered set (main.cpp:262-295).  rgb is the clipped estimate.
+__device__ void estimate(const PhotonMapView& pm, const WaveLds& L, int count, const double* nrm, const double* col, double norm, double* rgb,
+                         float* max_d2)
+{
+    const int lane = lane_id();
+    rgb[0] = rgb[1] = rgb[2] = 0.0;
+    *max_d2 = -1.f;
+    if (count == 0) return;                       // maxDistSqr stays -1, nothing is added (main.cpp:266,288)
+    float m = 0.f;
+    for (int j = lane; j < count; j += WAVE) m = fmaxf(m, L.key[j]);
+    const float maxDistSqr = wave_max(m);          // distance of the farthest returned photon (main.cpp:266-267)
+    *max_d2 = maxDistSqr;
+    const double denom = 1 - pow(2.71828, -1.953);
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int j = lane; j < count; j += WAVE) {
+        float distanceSqr = L.key[j];
+        const float* a = pm.aux + 6 * (size_t)L.idx[j];
+        // gaussian filter, main.cpp:279 (float result of a double expression)
+        float weight = (float)(0.918 * (1 - (1 - pow(2.71828, -1.953 * (distanceSqr) / (2 * maxDistSqr))) / denom));
+        float cosine = (float)(nrm[0] * (-(double)a[3]) + nrm[1] * (-(double)a[4]) + nrm[2] * (-(double)a[5]));   // main.cpp:281-283
+        if (cosine < 0) cosine = -cosine;
+        double sc = (double)(cosine * weight);
+        s0 += (col[0] * (double)a[0]) * sc;        // main.cpp:286
+        s1 += (col[1] * (double)a[1]) * sc;
+        s2 += (col[2] * (double)a[2]) * sc;
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+    double scale = 1.0 / (norm * maxDistSqr);      // main.cpp:293
+    double v[3] = {s0 * scale, s1 * scale, s2 * scale};
+    for (int c = 0; c < 3; c++) {                  // Color::clip, Color.h:39-57
+        double x = v[c];
+        if (x > 1) x = 1;
+        if (x < 0) x = 0;
+        rgb[c] = x;
+    }
+}
+
+// Gather queue consumer: acc[3*pixel..] += weight * clip(estimate)
+__global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const GatherRec* __restrict__ recs, const unsigned long long* n_recs,
+                                                      unsigned long long* next, GatherParams gp, double* __restrict__ acc)
+{
+    __shared__ WaveLds L;
+    const int lane = lane_id();
+    const unsigned long long n = *n_recs;
+    while (true) {
+        unsigned long long q = 0;
+        if (lane == 0) q = atomicAdd(next, 1ull);
+        q = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q);
+        if (q >= n) break;
+        const GatherRec& r = recs[q];
+        int count;
+        knn_collect(pm, L, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, count);
+        __builtin_amdgcn_wave_barrier();
+        double rgb[3];
+        float md2;
+        estimate(pm, L, count, r.normal, r.color, gp.norm, rgb, &md2);
+        if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * rgb[lane]);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Batch form for the ABI test hooks: query q -> count, max d2, clipped estimate
+__global__ __launch_bounds__(WAVE) void knn_batch_kernel(PhotonMapView pm, long long n, const double* __restrict__ pos, const double* __restrict__ nrm,
+                                                         const double* __restrict__ col, GatherParams gp, int* __restrict__ counts,
+                                                         double* __restrict__ r2_out, double* __restrict__ rgb_out, unsigned long long* next)
+{
+    __shared__ WaveLds L;
+    const int lane = lane_id();
+    while (true) {
+        unsigned long long q = 0;
+        if (lane == 0) q = atomicAdd(next, 1ull);
+        q = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q);
+        if (q >= (unsigned long long)n) break;
+        int count;
+        knn_collect(pm, L, (float)pos[3 * q], (float)pos[3 * q + 1], (float)pos[3 * q + 2], gp.k, gp.r2, count);
+        __builtin_amdgcn_wave_barrier();
+        double rgb[3] = {0, 0, 0};
+        float md2 = -1.f;
+        if (nrm && col) {
+            double nn[3] = {nrm[3 * q], nrm[3 * q + 1], nrm[3 * q + 2]}, cc[3] = {col[3 * q], col[3 * q + 1], col[3 * q + 2]};
+            estimate(pm, L, count, nn, cc, gp.norm, rgb, &md2);
+        } else if (count > 0) {
+            float m = 0.f;
+            for (int j = lane; j < count; j += WAVE) m = fmaxf(m, L.key[j]);
+            md2 = wave_max(m);
+        }
+        if (lane == 0) {
+            counts[q] = count;
+            if (r2_out) r2_out[q] = (double)md2;
+        }
+        if (rgb_out && lane < 3) rgb_out[3 * q + lane] = rgb[lane];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace rtg

@@ -60,7 +60,9 @@ template <class R>
 RT_HD R slab_finite(const R* lo, const R* hi, const R* o, const R* inv, R current_best)
 {
     R t0 = 0, t1 = current_best;
+#ifdef __HIPCC__
 #pragma unroll
+#endif
     for (int i = 0; i < 3; i++) {
         R a = (lo[i] - o[i]) * inv[i];
         R b = (hi[i] - o[i]) * inv[i];

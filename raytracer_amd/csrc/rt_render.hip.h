@@ -1,0 +1,256 @@
+// Pixel path as a wavefront of queues in HBM (replaces the recursion of getColorAt, main.cpp:158-392):
+//
+//   render_primary_kernel   camera rays (main.cpp:753-790) + BVH::Shoot -> hit queue level 1
+//   shade_level_kernel x D  per queued hit: colour, normal, material branch (main.cpp:164-258);
+//                           mirror / glass hits trace their reflection / refraction ray at once and
+//                           append the next level's hits (ballot-compacted); diffuse hits append a
+//                           gather request
+//   gather_kernel           photon k-NN + radiance estimate per request (rt_gather.hip.h)
+//   resolve_kernel          average, clip, quantise (main.cpp:853-859, IO.cpp:55-65)
+//
+// A path's contribution is carried as a scalar throughput `weight` (products of (2 - special),
+// (special - 1) or 1, main.cpp:200-203,251) and added to its pixel with a double atomic; the
+// per-level Color::clip of the recursion only ever sees sums of weights <= 1 times values <= 1.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_gather.hip.h"
+#include "rt_kernels.hip.h"
+
+namespace rtr {
+
+using rtk::BLOCK;
+using rtk::LaneStack;
+using rtk::WAVE;
+
+constexpr int MAX_LEVELS = 8;
+
+struct HitRec {
+    double pos[3];      // intersection position handed to getColorAt
+    double dir[3];      // direction of the ray that found it
+    double weight;
+    uint32_t pixel;     // index in the call's row block
+    int32_t obj;        // object to shade
+};
+
+struct RenderCounters {
+    unsigned long long next_primary;
+    unsigned long long next_level[MAX_LEVELS + 1];
+    unsigned long long next_gather;
+    unsigned long long n_hits[MAX_LEVELS + 2];   // n_hits[d] = queue length of level d (1-based)
+    unsigned long long n_gather;
+    unsigned long long overflow_stack, overflow_queue;
+    unsigned long long secondary_rays;
+    unsigned long long pad[3];
+};
+
+struct ShadeData {
+    const rtf::ObjShade* objs;
+    const rtf::TexDesc* maps;
+    const double* texels;
+};
+
+struct RenderArgs {
+    double cam_pos[3], cam_dir[3], cam_right[3], cam_down[3];
+    int width, height, row_begin, row_end;
+    int band_rows, n_parts, part;
+    int aadepth;
+    double accuracy;
+    int head_quirk, use_photon_map;
+};
+
+__device__ __forceinline__ unsigned prefix_rank(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// wave-aggregated append: one atomic per wave, lanes write at base + rank
+template <class T>
+__device__ __forceinline__ void queue_push(T* q, unsigned long long* n, unsigned long long cap, bool want, const T& rec, unsigned long long* overflow)
+{
+    unsigned long long m = __ballot(want);
+    if (m == 0) return;
+    unsigned long long base = 0;
+    int leader = __builtin_ctzll(m);
+    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(n, (unsigned long long)__builtin_popcountll(m));
+    unsigned lo = __shfl((unsigned)base, leader), hi = __shfl((unsigned)(base >> 32), leader);
+    base = ((unsigned long long)hi << 32) | lo;
+    if (want) {
+        unsigned long long p = base + prefix_rank(m);
+        if (p < cap) q[p] = rec;
+        else *overflow = 1;
+    }
+}
+
+template <class R>
+__global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits, unsigned long long cap_hits,
+                                                               RenderCounters* ctr, int cap)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    LaneStack st = rtk::make_stack<R>(lds, cap);
+    uint32_t ovf_stack = 0;
+    unsigned long long ovf_queue = 0;
+    const int rows = a.row_end - a.row_begin;
+    const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
+    const unsigned long long n_tiles = (unsigned long long)tiles_x * tiles_y;
+    while (true) {
+        unsigned long long tile = rtk::wave_fetch(&ctr->next_primary, 1, st.lane);
+        if (tile >= n_tiles) break;
+        int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+        int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
+        bool inside = x < a.width && yl < rows;
+        int yc = a.row_begin + yl;
+        int y = a.band_rows > 0 ? ((yc / a.band_rows) * a.n_parts + a.part) * a.band_rows + yc % a.band_rows : yc;
+        // The reference shoots aadepth^2 samples of which only aadepth are distinct (both offsets use
+        // aax, main.cpp:775-785): each distinct ray is traced once and weighted by its multiplicity.
+        for (int aax = 0; aax < a.aadepth; aax++) {
+            HitRec rec;
+            bool want = false;
+            if (inside) {
+                rtm::D3 dd = rtm::camera_ray_dir(a.cam_dir, a.cam_right, a.cam_down, a.width, a.height, a.aadepth, x, y, aax);
+                R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
+                R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
+                R dist = R(1e9);
+                int id = rtk::trace_ray<R>(sv, o, d, dist, st, &ovf_stack);
+                if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
+                    double t = (double)dist;
+                    rec.pos[0] = a.cam_pos[0] + dd.x * t; rec.pos[1] = a.cam_pos[1] + dd.y * t; rec.pos[2] = a.cam_pos[2] + dd.z * t;   // :821
+                    rec.dir[0] = dd.x; rec.dir[1] = dd.y; rec.dir[2] = dd.z;
+                    rec.weight = (double)a.aadepth;
+                    rec.pixel = (uint32_t)((long long)yl * a.width + x);
+                    rec.obj = id;
+                    want = true;
+                }
+            }
+            queue_push(hits, &ctr->n_hits[1], cap_hits, want, rec, &ovf_queue);
+        }
+    }
+    if (ovf_stack) atomicMax(&ctr->overflow_stack, 1ull);
+    if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
+}
+
+// One recursion level of getColorAt for every queued hit.
+template <class R>
+__global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv, ShadeData sd, RenderArgs a, int level, int last_level,
+                                                            const HitRec* __restrict__ in, HitRec* __restrict__ out, unsigned long long cap_hits,
+                                                            rtg::GatherRec* __restrict__ gq, unsigned long long cap_gq, RenderCounters* ctr, int cap)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    LaneStack st = rtk::make_stack<R>(lds, cap);
+    uint32_t ovf_stack = 0;
+    unsigned long long ovf_queue = 0, n_secondary = 0;
+    const unsigned long long n_in = ctr->n_hits[level] < cap_hits ? ctr->n_hits[level] : cap_hits;
+    while (true) {
+        unsigned long long base = rtk::wave_fetch(&ctr->next_level[level], WAVE, st.lane);
+        if (base >= n_in) break;
+        unsigned long long i = base + st.lane;
+        bool active = i < n_in;
+        HitRec next[2];
+        bool want[2] = {false, false};
+        rtg::GatherRec g;
+        bool want_g = false;
+        if (active) {
+            HitRec rec = in[i];
+            rtm::D3 hit_dir = {rec.dir[0], rec.dir[1], rec.dir[2]};
+            rtm::D3 hit_pos = rtm::vadd(rtm::D3{rec.pos[0], rec.pos[1], rec.pos[2]}, rtm::vmul(hit_dir, a.accuracy));   // main.cpp:162
+            const rtf::ObjShade& obj = sd.objs[rec.obj];
+            double col[4];
+            rtm::obj_color(obj, sd.maps, sd.texels, hit_pos, col);                 // main.cpp:164
+            rtm::D3 hit_normal = rtm::obj_normal(obj, hit_pos);                    // main.cpp:165
+            double special = col[3];
+            if (special > 0) {
+                if (!last_level) {   // children of the last level return black (main.cpp:161): not traced
+                    rtm::D3 Rd = rtm::reflect_dir(hit_normal, hit_dir);            // main.cpp:170
+                    R o[3] = {(R)hit_pos.x, (R)hit_pos.y, (R)hit_pos.z};
+                    {
+                        R d[3] = {(R)Rd.x, (R)Rd.y, (R)Rd.z};
+                        R dist = R(1e9);
+                        int io = rtk::trace_ray<R>(sv, o, d, dist, st, &ovf_stack);   // main.cpp:190-191
+                        n_secondary++;
+                        double t = (double)dist;
+                        bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:193
+                        if (go) {
+                            rtm::D3 np = rtm::vadd(hit_pos, rtm::vmul(Rd, t));     // main.cpp:195
+                            next[0].pos[0] = np.x; next[0].pos[1] = np.y; next[0].pos[2] = np.z;
+                            next[0].dir[0] = Rd.x; next[0].dir[1] = Rd.y; next[0].dir[2] = Rd.z;
+                            next[0].weight = special > 1 ? rec.weight * (2 - special) : rec.weight;   // main.cpp:200-203
+                            next[0].pixel = rec.pixel;
+                            next[0].obj = a.head_quirk ? rec.obj : io;             // main.cpp:198
+                            want[0] = true;
+                        }
+                    }
+                    if (special > 1) {                                             // main.cpp:210-258
+                        double refractance = special - 1;
+                        double n1n2 = 1.0 / obj.ior;
+                        double dot1 = rtm::vdot(hit_normal, rtm::vneg(hit_dir));
+                        if (dot1 < 0) {
+                            hit_normal = rtm::vneg(hit_normal);
+                            dot1 = rtm::vdot(hit_normal, rtm::vneg(hit_dir));
+                            n1n2 = 1.0 / n1n2;
+                        }
+                        double nNL = n1n2 * dot1;
+                        double underSQRT = 1 - n1n2 * n1n2 * (1 - dot1 * dot1);
+                        if (underSQRT > 0) {
+                            double coeffN = nNL - sqrt(underSQRT);
+                            rtm::D3 T = rtm::vadd(rtm::vmul(hit_normal, coeffN), rtm::vneg(rtm::vmul(rtm::vneg(hit_dir), n1n2)));   // main.cpp:233
+                            R d[3] = {(R)T.x, (R)T.y, (R)T.z};
+                            R dist = R(1e9);
+                            int io = rtk::trace_ray<R>(sv, o, d, dist, st, &ovf_stack);   // main.cpp:242-243
+                            n_secondary++;
+                            double t = (double)dist;
+                            bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:245
+                            if (go) {
+                                rtm::D3 np = rtm::vadd(hit_pos, rtm::vmul(T, a.accuracy + t));   // main.cpp:246
+                                next[1].pos[0] = np.x; next[1].pos[1] = np.y; next[1].pos[2] = np.z;
+                                next[1].dir[0] = T.x; next[1].dir[1] = T.y; next[1].dir[2] = T.z;
+                                next[1].weight = rec.weight * refractance;          // main.cpp:251
+                                next[1].pixel = rec.pixel;
+                                next[1].obj = a.head_quirk ? rec.obj : io;          // main.cpp:249
+                                want[1] = true;
+                            }
+                        }
+                    }
+                }
+            } else if (a.use_photon_map) {                                         // main.cpp:260-295
+                g.pos[0] = hit_pos.x; g.pos[1] = hit_pos.y; g.pos[2] = hit_pos.z;
+                g.normal[0] = hit_normal.x; g.normal[1] = hit_normal.y; g.normal[2] = hit_normal.z;
+                g.color[0] = col[0]; g.color[1] = col[1]; g.color[2] = col[2];
+                g.weight = rec.weight;
+                g.pixel = rec.pixel;
+                g.pad = 0;
+                want_g = true;
+            }
+        }
+        queue_push(out, &ctr->n_hits[level + 1], cap_hits, want[0], next[0], &ovf_queue);
+        queue_push(out, &ctr->n_hits[level + 1], cap_hits, want[1], next[1], &ovf_queue);
+        queue_push(gq, &ctr->n_gather, cap_gq, want_g, g, &ovf_queue);
+    }
+    if (ovf_stack) atomicMax(&ctr->overflow_stack, 1ull);
+    if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
+    for (int off = 32; off > 0; off >>= 1) n_secondary += __shfl_down(n_secondary, off);
+    if (st.lane == 0 && n_secondary) atomicAdd(&ctr->secondary_rays, n_secondary);
+}
+
+// Pixel average (main.cpp:853-859), clip (Color.h:39-57; a no-op after per-sample clipping) and the
+// quantiser of saveBmp: (unsigned char) floor(v * 255), written B, G, R (IO.cpp:58-62).
+__global__ void resolve_kernel(long long n_px, int aadepth, double* __restrict__ acc, double* __restrict__ rgb, uint8_t* __restrict__ bgr)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_px) return;
+    double v[3];
+    for (int c = 0; c < 3; c++) {
+        double x = acc[3 * i + c];
+        if (aadepth > 1) x = x / (double)(aadepth * aadepth);
+        if (x > 1) x = 1;
+        if (x < 0) x = 0;
+        v[c] = x;
+    }
+    if (rgb) { rgb[3 * i] = v[0]; rgb[3 * i + 1] = v[1]; rgb[3 * i + 2] = v[2]; }
+    if (bgr) {
+        bgr[3 * i] = (uint8_t)floor(v[2] * 255);
+        bgr[3 * i + 1] = (uint8_t)floor(v[1] * 255);
+        bgr[3 * i + 2] = (uint8_t)floor(v[0] * 255);
+    }
+}
+
+}  // namespace rtr

@@ -1,0 +1,61 @@
+"""Row tiling of one frame over the GPUs of a node (host logic, no device code).
+
+Image rows are dealt to the ranks in bands of BAND rows: band b belongs to rank b % n_parts.  Every
+rank renders its bands into one compact buffer [part_rows, width, ...]; rank 0 gathers the buffers
+(RCCL: each rank sends straight to rank 0 over its own xGMI link, no ring) and de-interleaves.
+The scene is replicated, so there is no other exchange.
+"""
+import math
+
+BAND = 8
+
+
+def frame_size(n_gpus, base=(1920, 1080)):
+    """Weak scaling: the frame grows by sqrt(n) per dimension so the rays per GPU stay constant;
+    width is a multiple of 8, height a multiple of BAND * n_gpus."""
+    s = math.sqrt(n_gpus)
+    w = int(round(base[0] * s / 8)) * 8
+    q = BAND * n_gpus
+    h = int(round(base[1] * s / q)) * q
+    return w, h
+
+
+def part_rows(height, n_parts):
+    assert height % (BAND * n_parts) == 0
+    return height // n_parts
+
+
+def rows_of_part(height, n_parts, part, band=BAND):
+    """Global row index of every compact row of `part`, in compact order."""
+    out = []
+    for yc in range(height // n_parts):
+        out.append(((yc // band) * n_parts + part) * band + yc % band)
+    return out
+
+
+def deinterleave(parts, band=BAND):
+    """parts: list (one per rank, in rank order) of arrays/tensors [part_rows, width, ...] ->
+    [height, width, ...] in image row order."""
+    n = len(parts)
+    first = parts[0]
+    pr = first.shape[0]
+    nb = pr // band
+    if hasattr(first, "new_empty"):     # torch tensors
+        import torch
+        stacked = torch.stack([p.reshape(nb, band, *p.shape[1:]) for p in parts], dim=1)
+    else:
+        import numpy as np
+        stacked = np.stack([p.reshape(nb, band, *p.shape[1:]) for p in parts], axis=1)
+    return stacked.reshape(pr * n, *first.shape[1:])
+
+
+def gather_to_rank0(buf, world, rank, dist, out=None):
+    """torch.distributed gather of equally sized per-rank buffers to rank 0 (list on rank 0, None
+    elsewhere).  `out`: optional preallocated receive list on rank 0, reused across frames."""
+    if world == 1:
+        return [buf]
+    import torch
+    if rank == 0 and out is None:
+        out = [torch.empty_like(buf) for _ in range(world)]
+    dist.gather(buf, out if rank == 0 else None, dst=0)
+    return out if rank == 0 else None
