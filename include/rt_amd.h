@@ -136,6 +136,10 @@ int rt_scene_build_bvh(rt_scene* s);
  * Call with NULL buffers to get the sizes. */
 int rt_scene_bvh_dump(const rt_scene* s, int32_t* rec, int64_t* n_rec, double* boxes, int64_t* n_boxes);
 int rt_scene_bvh_depth(const rt_scene* s);
+/* read a triangle back: points = A,B,C (as stored after the (A,C,B) constructor order), normals =
+ * NA,NB,NC, uvs = tA,tB,tC; flags bit 0: setNormals was called, bit 1: setTexture was called.
+ * Lets ObjReader::ReadContent (IO.h:61) hand API objects to the caller from the library's parser. */
+int rt_scene_get_triangle(const rt_scene* s, int obj, double points[9], double normals[9], double uvs[6], int* flags);
 
 /* Photon emission, main.cpp:396-598 + the loop of main.cpp:697-718, on the host (it is RNG-order
  * dependent): n_emit photons from light_pos, one thread, std::mt19937 seeded with `seed` (the
@@ -177,6 +181,9 @@ int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photo
 /* KDTree::findKNN(k, center), Kdtree.cpp:135, for a batch: counts[n], and (optional) the squared
  * distance of the farthest returned photon r2[n] (-1 when none). */
 int rt_knn_radius(rt_context* ctx, int which, int k, double max_dist, int64_t n, const double* centers, int32_t* counts, double* r2);
+/* KDTree::findKNN returning the set itself: idx is n x k indices into the uploaded photon array
+ * (-1 padded, unordered); counts[n]. */
+int rt_knn_query(rt_context* ctx, int which, int k, double max_dist, int64_t n, const double* centers, int32_t* idx, int32_t* counts);
 /* findKNN + the radiance estimate of main.cpp:260-295 for a batch of diffuse hits:
  * pos/normal n x 3, color n x 3 (hit colour), rgb out n x 3 (clipped as Color::clip) */
 int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal,

@@ -67,6 +67,7 @@ PROTOTYPES = {
     "rt_scene_build_bvh": (c_i, [vp]),
     "rt_scene_bvh_dump": (c_i, [vp, P(c_i32), P(c_i64), P(c_d), P(c_i64)]),
     "rt_scene_bvh_depth": (c_i, [vp]),
+    "rt_scene_get_triangle": (c_i, [vp, c_i, P(c_d), P(c_d), P(c_d), P(c_i)]),
     "rt_scene_emit_photons": (c_i, [vp, c_i64, P(c_d), ctypes.c_uint32, c_i, c_d]),
     "rt_scene_photon_count": (c_i64, [vp, c_i]),
     "rt_scene_photons_get": (c_i, [vp, c_i, P(c_d)]),
@@ -78,6 +79,7 @@ PROTOTYPES = {
     "rt_trace_primary": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, P(c_i32), P(c_d), P(c_i32), P(Stats)]),
     "rt_photons_upload": (c_i, [vp, c_i, c_i64, P(c_d)]),
     "rt_knn_radius": (c_i, [vp, c_i, c_i, c_d, c_i64, P(c_d), P(c_i32), P(c_d)]),
+    "rt_knn_query": (c_i, [vp, c_i, c_i, c_d, c_i64, P(c_d), P(c_i32), P(c_i32)]),
     "rt_knn_estimate": (c_i, [vp, P(RenderParams), c_i64, P(c_d), P(c_d), P(c_d), P(c_d), P(c_i32)]),
     "rt_render_rows_dev": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, vp, vp, P(Stats)]),
     "rt_render_rows": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, P(c_d), P(c_u8), P(Stats)]),

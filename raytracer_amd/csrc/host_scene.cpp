@@ -50,6 +50,7 @@ int Scene::set_texture(int obj, const double* ta, const double* tc, const double
     s.tA[0] = ta[0]; s.tA[1] = ta[1]; s.tB[0] = tb[0]; s.tB[1] = tb[1]; s.tC[0] = tc[0]; s.tC[1] = tc[1];
     s.has_texture = use ? 1 : 0;
     s.map = map;
+    objects[obj].has_uv = true;
     return 0;
 }
 
@@ -198,6 +199,7 @@ int Scene::load_obj(const char* path, const double* rgbs, float ior, float xo, f
                 s.tB[0] = uvs[vt[2]][0]; s.tB[1] = uvs[vt[2]][1];
                 s.has_texture = (use_texture && map >= 0 && map < (int)textures.size()) ? 1 : 0;
                 s.map = map;
+                objects[id].has_uv = true;
             }
         }
     }

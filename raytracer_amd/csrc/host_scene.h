@@ -16,6 +16,7 @@ struct Texture { int x_res = 0, y_res = 0; std::vector<double> rgb; };
 // One scene object in insertion order (the reference's scene_objects index, main.cpp:46).
 struct Object {
     rtf::ObjShade sh;   // geometry + material as the kernels see it
+    bool has_uv = false;   // texture coordinates were given (setTexture), whether or not a map is used
 };
 
 struct FlatBVH {

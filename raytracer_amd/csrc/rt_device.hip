@@ -88,7 +88,7 @@ struct rt_context {
     bool has_scene = false;
     DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
     // photon maps in HBM (0 surface, 1 volume)
-    DevBuf ph_pos[2], ph_aux[2], ph_axis[2];
+    DevBuf ph_pos[2], ph_aux[2], ph_axis[2], ph_order[2];
     rtg::PhotonMapView pm[2] = {};
     // render queues
     DevBuf hits_a, hits_b, gq, acc;
@@ -218,7 +218,7 @@ void rt_context_destroy(rt_context* ctx)
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
                       &ctx->hits_b, &ctx->gq, &ctx->acc, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
-                      &ctx->ph_axis[1]})
+                      &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1]})
         b->release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -359,6 +359,20 @@ int rt_scene_bvh_dump(const rt_scene* s, int32_t* rec, int64_t* n_rec, double* b
     return RT_OK;
 }
 int rt_scene_bvh_depth(const rt_scene* s) { return (s && s->s.bvh.built) ? s->s.bvh.depth : -1; }
+
+int rt_scene_get_triangle(const rt_scene* s, int obj, double points[9], double normals[9], double uvs[6], int* flags)
+{
+    if (!s || obj < 0 || obj >= (int)s->s.objects.size()) return fail(RT_ERR_INVALID, "object %d out of range", obj);
+    const rth::Object& o = s->s.objects[obj];
+    if (o.sh.kind != rtf::PRIM_TRI) return fail(RT_ERR_INVALID, "object %d is not a triangle", obj);
+    for (int i = 0; i < 3; i++) {
+        if (points) { points[i] = o.sh.A[i]; points[3 + i] = o.sh.B[i]; points[6 + i] = o.sh.C[i]; }
+        if (normals) { normals[i] = o.sh.NA[i]; normals[3 + i] = o.sh.NB[i]; normals[6 + i] = o.sh.NC[i]; }
+    }
+    if (uvs) { uvs[0] = o.sh.tA[0]; uvs[1] = o.sh.tA[1]; uvs[2] = o.sh.tB[0]; uvs[3] = o.sh.tB[1]; uvs[4] = o.sh.tC[0]; uvs[5] = o.sh.tC[1]; }
+    if (flags) *flags = (o.sh.has_normal ? 1 : 0) | (o.has_uv ? 2 : 0);
+    return RT_OK;
+}
 
 int rt_scene_emit_photons(rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy)
 {
@@ -555,10 +569,12 @@ int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photo
     if ((rc = upload(ctx->ph_pos[which], fm.pos, ctx->stream))) return rc;
     if ((rc = upload(ctx->ph_aux[which], fm.aux, ctx->stream))) return rc;
     if ((rc = upload(ctx->ph_axis[which], fm.axis, ctx->stream))) return rc;
+    if ((rc = upload(ctx->ph_order[which], fm.order, ctx->stream))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pm[which].pos = (const float*)ctx->ph_pos[which].p;
     ctx->pm[which].aux = (const float*)ctx->ph_aux[which].p;
     ctx->pm[which].axis = (const uint8_t*)ctx->ph_axis[which].p;
+    ctx->pm[which].order = (const int*)ctx->ph_order[which].p;
     ctx->pm[which].n = n;
     return RT_OK;
 }
@@ -567,7 +583,7 @@ int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photo
 
 namespace {
 int knn_launch(rt_context* ctx, int which, int k, double max_dist, int photon_num, int64_t n, const double* pos, const double* nrm, const double* col,
-               int32_t* counts, double* r2, double* rgb)
+               int32_t* counts, double* r2, double* rgb, int32_t* idx = nullptr)
 {
     if (k < 1 || k > rtg::MAX_K) return fail(RT_ERR_LIMIT, "k = %d outside [1, %d]", k, rtg::MAX_K);
     int rc = use_device(ctx);
@@ -577,6 +593,7 @@ int knn_launch(rt_context* ctx, int which, int k, double max_dist, int photon_nu
     if ((rc = ctx->st_dir.reserve(b3 * 3))) return rc;          // normals | colours | rgb out
     if ((rc = ctx->st_dist.reserve((size_t)n * 8))) return rc;
     if ((rc = ctx->st_ids.reserve((size_t)n * 4))) return rc;
+    if (idx && (rc = ctx->st_aux.reserve((size_t)n * k * 4))) return rc;
     double* d_pos = (double*)ctx->st_org.p;
     double* d_nrm = (double*)ctx->st_dir.p;
     double* d_col = d_nrm + (size_t)n * 3;
@@ -592,11 +609,12 @@ int knn_launch(rt_context* ctx, int which, int k, double max_dist, int photon_nu
     int blocks = (int)std::min<int64_t>(n, (int64_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(rtg::knn_batch_kernel, dim3(blocks), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[which], (long long)n, d_pos,
                        nrm ? d_nrm : nullptr, col ? d_col : nullptr, gp, (int*)ctx->st_ids.p, (double*)ctx->st_dist.p, rgb ? d_rgb : nullptr,
-                       (unsigned long long*)ctx->counters.p);
+                       idx ? (int*)ctx->st_aux.p : nullptr, (unsigned long long*)ctx->counters.p);
     HIP_TRY(hipGetLastError());
     if (counts) HIP_TRY(hipMemcpyAsync(counts, ctx->st_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (r2) HIP_TRY(hipMemcpyAsync(r2, ctx->st_dist.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (rgb) HIP_TRY(hipMemcpyAsync(rgb, d_rgb, b3, hipMemcpyDeviceToHost, ctx->stream));
+    if (idx) HIP_TRY(hipMemcpyAsync(idx, ctx->st_aux.p, (size_t)n * k * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
 }
@@ -609,6 +627,13 @@ int rt_knn_radius(rt_context* ctx, int which, int k, double max_dist, int64_t n,
     if (!ctx || !centers || (which != 0 && which != 1) || n < 0) return fail(RT_ERR_INVALID, "bad argument");
     if (n == 0) return RT_OK;
     return knn_launch(ctx, which, k, max_dist, 16, n, centers, nullptr, nullptr, counts, r2, nullptr);
+}
+
+int rt_knn_query(rt_context* ctx, int which, int k, double max_dist, int64_t n, const double* centers, int32_t* idx, int32_t* counts)
+{
+    if (!ctx || !centers || !idx || (which != 0 && which != 1) || n < 0) return fail(RT_ERR_INVALID, "bad argument");
+    if (n == 0) return RT_OK;
+    return knn_launch(ctx, which, k, max_dist, 16, n, centers, nullptr, nullptr, counts, nullptr, nullptr, idx);
 }
 
 int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal, const double* color,

@@ -27,6 +27,7 @@ struct PhotonMapView {
     const float* pos;            // 3 per photon, tree order
     const float* aux;            // 6 per photon: power rgb, dir xyz
     const uint8_t* axis;
+    const int* order;            // tree position -> index in the caller's photon array
     long long n;
 };
 
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const Ga
         double rgb[3];
         float md2;
         estimate(pm, L, count, r.normal, r.color, gp.norm, rgb, &md2);
-        if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * rgb[lane]);
+        if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * (lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2])));
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -275,7 +276,8 @@ __global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const Ga
 // Batch form for the ABI test hooks: query q -> count, max d2, clipped estimate
 __global__ __launch_bounds__(WAVE) void knn_batch_kernel(PhotonMapView pm, long long n, const double* __restrict__ pos, const double* __restrict__ nrm,
                                                          const double* __restrict__ col, GatherParams gp, int* __restrict__ counts,
-                                                         double* __restrict__ r2_out, double* __restrict__ rgb_out, unsigned long long* next)
+                                                         double* __restrict__ r2_out, double* __restrict__ rgb_out, int* __restrict__ idx_out,
+                                                         unsigned long long* next)
 {
     __shared__ WaveLds L;
     const int lane = lane_id();
@@ -301,7 +303,10 @@ __global__ __launch_bounds__(WAVE) void knn_batch_kernel(PhotonMapView pm, long 
             counts[q] = count;
             if (r2_out) r2_out[q] = (double)md2;
         }
-        if (rgb_out && lane < 3) rgb_out[3 * q + lane] = rgb[lane];
+        if (rgb_out && lane < 3) rgb_out[3 * q + lane] = lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2]);
+        if (idx_out) {   // the set itself, in the caller's numbering, -1 padded to k
+            for (int j = lane; j < gp.k; j += WAVE) idx_out[(size_t)q * gp.k + j] = j < count ? pm.order[L.idx[j]] : -1;
+        }
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -1,0 +1,43 @@
+// Photon kd-tree of the scene API (reference: Kdtree.h:25-73, Kdtree.cpp:11-158).  The constructor
+// flattens the photons into the GPU photon map (rt_photons_upload); findKNN returns the k nearest
+// photons within PHOTONDIST = 0.28 of `center`, nearest first, as borrowed pointers.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+#include "Device.h"
+#include "Photon.h"
+#include "Vect.h"
+
+class KDTree {
+    std::vector<Photon*> photons;   // borrowed
+    int which;
+
+public:
+    // which: 0 = surface map (`kdtree`, main.cpp:724), 1 = volume map (`volumeKDTree`, main.cpp:727)
+    KDTree(std::vector<Photon*>& in_photons, int which_map = 0) : photons(in_photons), which(which_map) { createKD(in_photons); }
+
+    void createKD(std::vector<Photon*>& in_photons)
+    {
+        photons = in_photons;
+        std::vector<double> flat(photons.size() * 9);
+        for (size_t i = 0; i < photons.size(); i++) {
+            const Photon* p = photons[i];
+            double* f = &flat[i * 9];
+            for (int c = 0; c < 3; c++) { f[c] = p->position[c]; f[6 + c] = p->dir[c]; }
+            f[3] = p->power.getColorRed(); f[4] = p->power.getColorGreen(); f[5] = p->power.getColorBlue();
+        }
+        rt::check(rt_photons_upload(rt::device(), which, (int64_t)photons.size(), flat.data()), "rt_photons_upload");
+    }
+
+    std::vector<Photon*> findKNN(int k, Vect center) const
+    {
+        std::vector<int32_t> idx((size_t)k);
+        int32_t count = 0;
+        rt::check(rt_knn_query(rt::device(), which, k, 0.28, 1, center.data(), idx.data(), &count), "rt_knn_query");
+        std::vector<Photon*> out;
+        for (int i = 0; i < count; i++) out.push_back(photons[(size_t)idx[i]]);
+        std::sort(out.begin(), out.end(), [&](const Photon* a, const Photon* b) { return a->position.sqrDist(center) < b->position.sqrDist(center); });
+        return out;
+    }
+};
