@@ -2,6 +2,10 @@
 
 Plumbing only: loads the in-tree shared library and declares the prototypes.  There is no
 fallback of any kind -- if the library is missing, importing this module raises.
+
+A process that also uses torch must import torch (and initialise its GPU runtime) BEFORE this
+module: the torch wheel bundles its own HIP runtime, and the runtime loaded first is the one
+that owns the devices.
 """
 import ctypes
 import os

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -84,6 +85,7 @@ struct rt_context {
     rtf::SceneView<double> v64{};
     rtf::SceneView<float> v32{};
     int depth = 0;
+    int n_nodes = 0;
     int n_objects = 0;
     bool has_scene = false;
     DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
@@ -134,10 +136,54 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
     size_t lds = rtk::stack_lds_bytes(cap, sizeof(R));
     if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
     HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
-    int blocks = (int)std::min<int64_t>(grid_blocks(ctx, lds), (n + rtk::BLOCK - 1) / rtk::BLOCK);
-    if (blocks < 1) blocks = 1;
+    int blocks = (int)std::max<int64_t>(1, (n + rtk::BLOCK - 1) / rtk::BLOCK);   // one chunk of 64 rays per wave
     hipLaunchKernelGGL((rtk::trace_batch_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), (long long)n, d_org,
                        d_dir, d_dist, d_ids, (rtk::TraceCounters*)ctx->counters.p, cap);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// Launch geometry of the persistent traversal kernels.  LDS per block = node image (if staged) +
+// per-wave stacks; the block size is chosen to keep the most waves resident per CU.
+struct TraceGeom { int threads, blocks; size_t lds; bool nodes_in_lds; };
+
+template <class R>
+int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g)
+{
+    // Blocks of 4 waves (one 8x8 tile each); smaller blocks only when a deep tree's stacks would
+    // not fit. The node array is copied into each block's LDS when that copy is cheap next to the
+    // block's traversal work and leaves room for 3 blocks per CU.
+    const int cap = stack_cap(ctx);
+    const size_t per_wave = rtk::stack_lds_bytes(cap, sizeof(R), 1);
+    const size_t lds_max = 160 * 1024;
+    const size_t node_bytes = rtk::node_lds_bytes<R>((size_t)n_nodes);
+    for (int w : {4, 2, 1}) {
+        size_t lds = w * per_wave;
+        if (lds > lds_max) continue;
+        bool nlds = w == 4 && n_nodes > 0 && node_bytes <= 24 * 1024 && 3 * (lds + node_bytes) <= lds_max && !getenv("RT_NO_NODE_LDS");
+        *g = TraceGeom{w * 64, 0, lds + (nlds ? node_bytes : 0), nlds};
+        return RT_OK;
+    }
+    return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack per wave (> 160 KiB per block)", ctx->depth, per_wave);
+}
+
+template <class R, bool COUNT, bool TRI_ONLY>
+int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow)
+{
+    int cap = stack_cap(ctx);
+    TraceGeom g;
+    int rc = trace_geometry<R>(ctx, ctx->n_nodes, &g);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
+    int64_t tiles = (int64_t)((a.width + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
+    int wpb = g.threads / 64;
+    int blocks = (int)std::max<int64_t>(1, (tiles + wpb - 1) / wpb);
+    if (g.nodes_in_lds)
+        hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, true>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
+                           d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes);
+    else
+        hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, false>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
+                           d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes);
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -145,17 +191,8 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
 template <class R, bool COUNT>
 int launch_primary(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow)
 {
-    int cap = stack_cap(ctx);
-    size_t lds = rtk::stack_lds_bytes(cap, sizeof(R));
-    if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
-    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
-    int64_t tiles = (int64_t)((a.width + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
-    int blocks = (int)std::min<int64_t>(grid_blocks(ctx, lds), (tiles + rtk::WAVES_PER_BLOCK - 1) / rtk::WAVES_PER_BLOCK);
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a, d_ids, d_t,
-                       d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap);
-    HIP_TRY(hipGetLastError());
-    return RT_OK;
+    return view<R>(ctx).tri_only ? launch_primary_t<R, COUNT, true>(ctx, a, d_ids, d_t, d_shadow)
+                                 : launch_primary_t<R, COUNT, false>(ctx, a, d_ids, d_t, d_shadow);
 }
 
 int check_params(const rt_render_params* p)
@@ -442,7 +479,11 @@ int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
     }
     ctx->v64.root_ref = ctx->v32.root_ref = b.root_ref;
     ctx->v64.n_planes = ctx->v32.n_planes = (int32_t)b.planes.size();
+    bool tri_only = true;
+    for (const auto& pr : b.prims) tri_only = tri_only && pr.kind == rtf::PRIM_TRI;
+    ctx->v64.tri_only = ctx->v32.tri_only = tri_only ? 1 : 0;
     ctx->depth = b.depth;
+    ctx->n_nodes = (int)b.nodes.size();
     ctx->n_objects = (int)s.objects.size();
     ctx->has_scene = true;
     return RT_OK;
@@ -673,7 +714,9 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     int blocks = grid_blocks(ctx, lds);
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    hipLaunchKernelGGL((rtr::render_primary_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a,
+    const int64_t tiles = (int64_t)((a.width + 7) / 8) * ((rows + 7) / 8);
+    const int waves_per_block = rtk::BLOCK / 64;
+    hipLaunchKernelGGL((rtr::render_primary_kernel<R>), dim3((unsigned)((tiles + waves_per_block - 1) / waves_per_block)), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a,
                        (rtr::HitRec*)ctx->hits_a.p, cap_hits, ctr, cap);
     HIP_TRY(hipGetLastError());
     rtr::HitRec* qin = (rtr::HitRec*)ctx->hits_a.p;

@@ -70,6 +70,7 @@ struct SceneView {
     R root_lo[3], root_hi[3];
     uint32_t root_ref;
     int32_t n_planes;
+    int32_t tri_only;   // every primitive in the tree is a triangle (no per-primitive kind dispatch)
 };
 
 }  // namespace rtf

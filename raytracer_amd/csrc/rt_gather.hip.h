@@ -256,11 +256,19 @@ __global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const Ga
     __shared__ WaveLds L;
     const int lane = lane_id();
     const unsigned long long n = *n_recs;
+    unsigned long long q_begin = 0, q_end = 0;
     while (true) {
-        unsigned long long q = 0;
-        if (lane == 0) q = atomicAdd(next, 1ull);
-        q = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q);
-        if (q >= n) break;
+        // several queries per request on the shared counter, fewer near the end (see rtk::next_batch)
+        unsigned long long left = n > q_end ? n - q_end : 0;
+        unsigned long long want = left / (4ull * gridDim.x);
+        want = want < 1 ? 1 : (want > 16 ? 16 : want);
+        unsigned long long q0 = 0;
+        if (lane == 0) q0 = atomicAdd(next, want);
+        q0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q0);
+        if (q0 >= n) break;
+        q_begin = q0;
+        q_end = q0 + want < n ? q0 + want : n;
+      for (unsigned long long q = q_begin; q < q_end; q++) {
         const GatherRec& r = recs[q];
         int count;
         knn_collect(pm, L, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, count);
@@ -270,6 +278,7 @@ __global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const Ga
         estimate(pm, L, count, r.normal, r.color, gp.norm, rgb, &md2);
         if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * (lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2])));
         __builtin_amdgcn_wave_barrier();
+      }
     }
 }
 

@@ -15,13 +15,50 @@ namespace rtk {
 constexpr int WAVE = 64;
 constexpr int BLOCK = 256;
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+constexpr int MAX_BLOCK = 768;   // register budget of the traversal kernels: compiled for 3 waves per SIMD (<= 168 VGPRs)
 
 struct LaneStack {
     uint32_t* ref;   // [depth][64] for this wave
     void* t0;        // [depth][64] of R
+    const uint4* lds_nodes;   // node image in LDS (NLDS kernels), else unused
     int lane;
     int cap;
 };
+
+// Inner nodes staged in LDS (small trees): only the payload of a node is kept (float 56 -> 64 B read as
+// 4 chunks, double 104 -> 112 B as 7 chunks of 16 B) at a stride of an ODD number of 16-byte slots
+// (5 / 7), so that lanes reading different nodes spread over all 16 slots of the 256-byte bank row.
+template <class R> struct NodeLds;
+template <> struct NodeLds<float> { static constexpr int CHUNKS = 4, STRIDE = 5; };
+template <> struct NodeLds<double> { static constexpr int CHUNKS = 7, STRIDE = 7; };
+
+template <class R>
+__host__ __device__ inline size_t node_lds_bytes(size_t n_nodes) { return n_nodes * NodeLds<R>::STRIDE * 16; }
+
+template <class R>
+__device__ __forceinline__ void stage_nodes(uint4* dst, const rtf::Node<R>* nodes, int n_nodes)
+{
+    constexpr int CH = NodeLds<R>::CHUNKS, ST = NodeLds<R>::STRIDE, SRC = sizeof(rtf::Node<R>) / 16;
+    const uint4* src = reinterpret_cast<const uint4*>(nodes);
+    for (int i = threadIdx.x; i < n_nodes * CH; i += blockDim.x) {
+        int n = i / CH, c = i - n * CH;
+        dst[n * ST + c] = src[n * SRC + c];
+    }
+    __syncthreads();
+}
+
+template <class R, bool NLDS>
+__device__ __forceinline__ rtf::Node<R> fetch_node(const rtf::Node<R>* __restrict__ nodes, const uint4* lds_nodes, uint32_t idx)
+{
+    constexpr int CH = NodeLds<R>::CHUNKS, ST = NodeLds<R>::STRIDE;
+    uint4 v[sizeof(rtf::Node<R>) / 16];
+    const uint4* src = NLDS ? lds_nodes + (size_t)idx * ST : reinterpret_cast<const uint4*>(nodes + idx);
+#pragma unroll
+    for (int i = 0; i < CH; i++) v[i] = src[i];
+    rtf::Node<R> out;
+    __builtin_memcpy(&out, v, CH * 16);
+    return out;
+}
 
 template <class R> __device__ __forceinline__ bool rt_finite(R v);
 template <> __device__ __forceinline__ bool rt_finite<float>(float v) { return __builtin_isfinite(v); }
@@ -29,18 +66,39 @@ template <> __device__ __forceinline__ bool rt_finite<double>(double v) { return
 
 struct WorkCount { unsigned long long inner = 0, prims = 0; };
 
+// whole primitive record in 16-byte pieces issued back to back (one round trip instead of one per field)
+template <class R>
+__device__ __forceinline__ rtf::Prim<R> load_prim(const rtf::Prim<R>* p)
+{
+    constexpr int N = sizeof(rtf::Prim<R>) / 16;
+    static_assert(sizeof(rtf::Prim<R>) % 16 == 0, "primitive record is a multiple of 16 bytes");
+    uint4 v[N];
+    const uint4* src = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = src[i];
+    rtf::Prim<R> out;
+    __builtin_memcpy(&out, v, sizeof(out));
+    return out;
+}
+
 // Leaf: test every primitive in leaf order, accept iff t >= 0 && t < dist (BVH.cpp:135-149).
-template <class R, bool COUNT>
+// The next record is fetched while the current one is tested.
+template <class R, bool COUNT, bool TRI_ONLY>
 __device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims, uint32_t leaf, const R* o, const R* d, R& dist, int& hit,
                                           WorkCount* wc)
 {
     uint32_t first = leaf & rtf::LEAF_FIRST_MASK;
     uint32_t cnt = (leaf >> rtf::LEAF_COUNT_SHIFT) & 15u;
     if (COUNT) wc->prims += cnt;
+    rtf::Prim<R> cur = load_prim<R>(prims + first);
     for (uint32_t k = 0; k < cnt; k++) {
-        const rtf::Prim<R>& p = prims[first + k];
-        R t = rtm::prim_intersect<R>(p, o, d);
-        if (t >= R(0) && t < dist) { dist = t; hit = (int)p.id; }
+        rtf::Prim<R> nxt = cur;
+        if (k + 1 < cnt) nxt = load_prim<R>(prims + first + k + 1);
+        R t;
+        if (TRI_ONLY) t = rtm::tri_intersect_flat<R>(cur.a, cur.e1, cur.e2, o, d);
+        else t = cur.kind == rtf::PRIM_TRI ? rtm::tri_intersect_flat<R>(cur.a, cur.e1, cur.e2, o, d) : rtm::prim_intersect<R>(cur, o, d);
+        if (t >= R(0) && t < dist) { dist = t; hit = (int)cur.id; }
+        cur = nxt;
     }
 }
 
@@ -54,7 +112,7 @@ __device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims
 //     what the pop compares (t0 travels on the stack);
 //   - rays with a non-finite reciprocal direction or origin (axis-parallel rays: 0 * inf = NaN in
 //     the slab test) take the literal path below, which re-runs the full slab test on entry.
-template <class R, bool COUNT = false>
+template <class R, bool COUNT = false, bool TRI_ONLY = false, bool NLDS = false>
 __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R& dist, const LaneStack& st, uint32_t* overflow,
                          WorkCount* wc = nullptr)
 {
@@ -74,7 +132,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                 int sp = 0;
                 while (true) {
                     if (!(cur & rtf::LEAF_BIT)) {
-                        const rtf::Node<R>& nd = sv.nodes[cur];
+                        const rtf::Node<R> nd = fetch_node<R, NLDS>(sv.nodes, st.lds_nodes, cur);
                         if (COUNT) wc->inner++;
                         R td0 = rtm::slab_finite<R>(nd.lo0, nd.hi0, o, inv, dist);
                         R td1 = rtm::slab_finite<R>(nd.lo1, nd.hi1, o, inv, dist);
@@ -95,7 +153,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                         if (h0) { cur = c0; continue; }
                         if (h1) { cur = c1; continue; }
                     } else {
-                        test_leaf<R, COUNT>(sv.prims, cur, o, d, dist, hit, wc);
+                        test_leaf<R, COUNT, TRI_ONLY>(sv.prims, cur, o, d, dist, hit, wc);
                     }
                     bool found = false;
                     while (sp > 0) {
@@ -115,7 +173,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                 while (true) {
                     if (have) {
                         if (cur & rtf::LEAF_BIT) {
-                            test_leaf<R, COUNT>(sv.prims, cur, o, d, dist, hit, wc);
+                            test_leaf<R, COUNT, TRI_ONLY>(sv.prims, cur, o, d, dist, hit, wc);
                         } else {
                             const rtf::Node<R>& nd = sv.nodes[cur];
                             if (COUNT) wc->inner++;
@@ -163,19 +221,42 @@ __device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* cou
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// LDS layout of a block: [node image (node_bytes, may be 0)] [refs: waves x cap x 64 x 4 B] [t0: waves x cap x 64 x sizeof(R)]
+// Guided self-scheduling over [0, total): one returning atomic on a single word serves only ~90
+// requests per microsecond chip-wide, so waves take several units per request -- large batches
+// while plenty of work is left, single units near the end (load balance of the tail).
+struct WorkBatch {
+    unsigned long long begin = 0, end = 0;
+};
+__device__ __forceinline__ bool next_batch(WorkBatch& b, unsigned long long* counter, unsigned long long total, unsigned n_waves, int lane)
+{
+    // size from what was left when this wave last looked (first call: begin = end = 0 -> total / (4 waves))
+    unsigned long long left = total > b.end ? total - b.end : 0;
+    unsigned long long want = left / (4ull * n_waves);
+    want = want < 1 ? 1 : (want > 32 ? 32 : want);
+    unsigned long long base = wave_fetch(counter, want, lane);
+    if (base >= total) return false;
+    b.begin = base;
+    b.end = base + want < total ? base + want : total;
+    return true;
+}
+
 template <class R>
-__device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap)
+__device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, size_t node_bytes = 0)
 {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int waves = blockDim.x >> 6;
     LaneStack st;
-    st.ref = (uint32_t*)lds + (size_t)wave * cap * WAVE;
-    st.t0 = (void*)((R*)(lds + (size_t)WAVES_PER_BLOCK * cap * WAVE * sizeof(uint32_t)) + (size_t)wave * cap * WAVE);
+    st.lds_nodes = reinterpret_cast<const uint4*>(lds);
+    unsigned char* base = lds + node_bytes;
+    st.ref = (uint32_t*)base + (size_t)wave * cap * WAVE;
+    st.t0 = (void*)((R*)(base + (size_t)waves * cap * WAVE * sizeof(uint32_t)) + (size_t)wave * cap * WAVE);
     st.lane = lane;
     st.cap = cap;
     return st;
 }
 
-inline size_t stack_lds_bytes(int cap, size_t real_size) { return (size_t)WAVES_PER_BLOCK * cap * WAVE * (sizeof(uint32_t) + real_size); }
+inline size_t stack_lds_bytes(int cap, size_t real_size, int waves = WAVES_PER_BLOCK) { return (size_t)waves * cap * WAVE * (sizeof(uint32_t) + real_size); }
 
 // counters[0] = work counter, counters[1] = stack-overflow flag, counters[2] = shadow rays traced
 struct TraceCounters { unsigned long long next, overflow, shadow, inner, prims, pad[3]; };
@@ -189,18 +270,15 @@ __global__ __launch_bounds__(BLOCK) void trace_batch_kernel(rtf::SceneView<R> sv
     extern __shared__ __align__(16) unsigned char lds[];
     LaneStack st = make_stack<R>(lds, cap);
     uint32_t overflow = 0;
-    while (true) {
-        unsigned long long base = wave_fetch(&ctr->next, WAVE, st.lane);
-        if (base >= (unsigned long long)n) break;
-        long long i = (long long)base + st.lane;
-        if (i < n) {
-            R o[3] = {(R)org[i], (R)org[n + i], (R)org[2 * n + i]};
-            R d[3] = {(R)dir[i], (R)dir[n + i], (R)dir[2 * n + i]};
-            R dist = (R)dist_io[i];
-            int id = trace_ray<R>(sv, o, d, dist, st, &overflow);
-            ids[i] = id;
-            if (id >= 0) dist_io[i] = (double)dist;
-        }
+    // one chunk of 64 rays per wave; the dispatcher balances the load
+    long long i = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * WAVE + st.lane;
+    if (i < n) {
+        R o[3] = {(R)org[i], (R)org[n + i], (R)org[2 * n + i]};
+        R d[3] = {(R)dir[i], (R)dir[n + i], (R)dir[2 * n + i]};
+        R dist = (R)dist_io[i];
+        int id = trace_ray<R>(sv, o, d, dist, st, &overflow);
+        ids[i] = id;
+        if (id >= 0) dist_io[i] = (double)dist;
     }
     if (overflow) atomicMax(&ctr->overflow, 1ull);
 }
@@ -216,22 +294,26 @@ struct PrimaryArgs {
 // Pixel loop front end: camera ray (always generated in double, then rounded to R) + BVH::Shoot
 // with distance 1e9 (main.cpp:812-813); optional shadow ray toward the light.
 // Work unit = 8x8 pixel tile per wave.
-template <class R, bool COUNT>
-__global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> sv, PrimaryArgs a, int* __restrict__ ids,
-                                                              double* __restrict__ t_out, int* __restrict__ shadow_ids,
-                                                              TraceCounters* ctr, int cap)
+template <class R, bool COUNT, bool TRI_ONLY, bool NLDS>
+__global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView<R> sv, PrimaryArgs a, int* __restrict__ ids,
+                                                                  double* __restrict__ t_out, int* __restrict__ shadow_ids,
+                                                                  TraceCounters* ctr, int cap, int n_nodes)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    LaneStack st = make_stack<R>(lds, cap);
+    const size_t node_bytes = NLDS ? node_lds_bytes<R>((size_t)n_nodes) : 0;
+    if (NLDS) stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    LaneStack st = make_stack<R>(lds, cap, node_bytes);
     uint32_t overflow = 0;
     unsigned long long n_shadow = 0;
     WorkCount wc;
     const int rows = a.row_end - a.row_begin;
     const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
     const unsigned long long n_tiles = (unsigned long long)tiles_x * tiles_y;
-    while (true) {
-        unsigned long long tile = wave_fetch(&ctr->next, 1, st.lane);
-        if (tile >= n_tiles) break;
+    // one 8x8 tile per wave, no work counter: the hardware dispatcher balances the load by starting
+    // blocks as earlier ones retire (a shared counter serves only ~90 requests per microsecond
+    // chip-wide, which is fewer than the tiles this kernel retires)
+    const unsigned long long tile = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile < n_tiles) {
         int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
         int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
         if (x < a.width && yl < rows) {
@@ -241,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> 
             R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
             R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
             R dist = R(1e9);
-            int id = trace_ray<R, COUNT>(sv, o, d, dist, st, &overflow, &wc);
+            int id = trace_ray<R, COUNT, TRI_ONLY, NLDS>(sv, o, d, dist, st, &overflow, &wc);
             long long px = (long long)yl * a.width + x;
             ids[px] = id;
             if (t_out) t_out[px] = (double)dist;
@@ -259,7 +341,7 @@ __global__ __launch_bounds__(BLOCK) void trace_primary_kernel(rtf::SceneView<R> 
                     R o2[3] = {(R)so.x, (R)so.y, (R)so.z};
                     R d2[3] = {(R)L.x, (R)L.y, (R)L.z};
                     R range = (R)(len - 1e-4);
-                    sid = trace_ray<R, COUNT>(sv, o2, d2, range, st, &overflow, &wc);
+                    sid = trace_ray<R, COUNT, TRI_ONLY, NLDS>(sv, o2, d2, range, st, &overflow, &wc);
                     n_shadow++;
                 }
                 if (shadow_ids) shadow_ids[px] = sid;

@@ -20,6 +20,12 @@ template <class R> struct V3 { R x, y, z; };
 template <class R> RT_HD R rt_sqrt(R v);
 template <> RT_HD float rt_sqrt<float>(float v) { return sqrtf(v); }
 template <> RT_HD double rt_sqrt<double>(double v) { return sqrt(v); }
+template <class R> RT_HD R rt_min(R a, R b);
+template <> RT_HD float rt_min<float>(float a, float b) { return __builtin_fminf(a, b); }
+template <> RT_HD double rt_min<double>(double a, double b) { return __builtin_fmin(a, b); }
+template <class R> RT_HD R rt_max(R a, R b);
+template <> RT_HD float rt_max<float>(float a, float b) { return __builtin_fmaxf(a, b); }
+template <> RT_HD double rt_max<double>(double a, double b) { return __builtin_fmax(a, b); }
 template <class R> RT_HD R rt_abs(R v);
 template <> RT_HD float rt_abs<float>(float v) { return fabsf(v); }
 template <> RT_HD double rt_abs<double>(double v) { return fabs(v); }
@@ -66,10 +72,12 @@ RT_HD R slab_finite(const R* lo, const R* hi, const R* o, const R* inv, R curren
     for (int i = 0; i < 3; i++) {
         R a = (lo[i] - o[i]) * inv[i];
         R b = (hi[i] - o[i]) * inv[i];
-        R n = a < b ? a : b;
-        R f = a < b ? b : a;
-        t0 = n > t0 ? n : t0;
-        t1 = f > t1 ? t1 : f;
+        // no NaN can reach here, so min/max instructions give what the ternaries give (the sign of
+        // a zero is never observed: the results are only compared)
+        R n = rt_min<R>(a, b);
+        R f = rt_max<R>(a, b);
+        t0 = rt_max<R>(n, t0);
+        t1 = rt_min<R>(f, t1);
     }
     return t0 > t1 ? R(-1) : t0;
 }
@@ -93,6 +101,28 @@ RT_HD R tri_intersect(const R* A, const R* e1, const R* e2, const R* o, const R*
     R v = f * (d[0] * rx + d[1] * ry + d[2] * rz);
     if (v < R(0) || u + v > R(1)) return R(-1);
     return f * (rx * e2[0] + ry * e2[1] + rz * e2[2]);
+}
+
+// The same test without branches, for SIMD execution: everything is computed, the reference's
+// rejections are applied at the end as the exact negations of its conditions (so NaNs behave the
+// same: a NaN never rejects, it flows into the returned t, which the caller's `t >= 0` drops).
+template <class R>
+RT_HD R tri_intersect_flat(const R* A, const R* e1, const R* e2, const R* o, const R* d)
+{
+    R qx = d[1] * e2[2] - d[2] * e2[1];
+    R qy = d[2] * e2[0] - d[0] * e2[2];
+    R qz = d[0] * e2[1] - d[1] * e2[0];
+    R a = e1[0] * qx + e1[1] * qy + e1[2] * qz;
+    R f = R(1) / a;
+    R sx = o[0] - A[0], sy = o[1] - A[1], sz = o[2] - A[2];
+    R u = f * (sx * qx + sy * qy + sz * qz);
+    R rx = sy * e1[2] - sz * e1[1];
+    R ry = sz * e1[0] - sx * e1[2];
+    R rz = sx * e1[1] - sy * e1[0];
+    R v = f * (d[0] * rx + d[1] * ry + d[2] * rz);
+    R t = f * (rx * e2[0] + ry * e2[1] + rz * e2[2]);
+    bool reject = (rt_abs<R>(a) < R(0.00001)) || (u < R(0)) || (v < R(0) || u + v > R(1));
+    return reject ? R(-1) : t;
 }
 
 // Sphere::findIntersection (Sphere.h:44-90): origin pre-offset by 0.1 * dir, and the second root

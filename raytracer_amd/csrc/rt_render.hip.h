@@ -93,9 +93,9 @@ __global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R>
     const int rows = a.row_end - a.row_begin;
     const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
     const unsigned long long n_tiles = (unsigned long long)tiles_x * tiles_y;
-    while (true) {
-        unsigned long long tile = rtk::wave_fetch(&ctr->next_primary, 1, st.lane);
-        if (tile >= n_tiles) break;
+    // one 8x8 tile per wave; the dispatcher balances the load
+    const unsigned long long tile = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile < n_tiles) {
         int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
         int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
         bool inside = x < a.width && yl < rows;
@@ -140,10 +140,12 @@ __global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0, n_secondary = 0;
     const unsigned long long n_in = ctr->n_hits[level] < cap_hits ? ctr->n_hits[level] : cap_hits;
-    while (true) {
-        unsigned long long base = rtk::wave_fetch(&ctr->next_level[level], WAVE, st.lane);
-        if (base >= n_in) break;
-        unsigned long long i = base + st.lane;
+    const unsigned long long chunks = (n_in + WAVE - 1) / WAVE;
+    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
+    // the queue length lives in device memory, so the grid is persistent; chunks are dealt round-robin
+    // to the waves (no work counter: one word serves only ~90 requests per microsecond chip-wide)
+    for (unsigned long long chunk = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); chunk < chunks; chunk += n_waves) {
+        unsigned long long i = chunk * WAVE + st.lane;
         bool active = i < n_in;
         HitRec next[2];
         bool want[2] = {false, false};
