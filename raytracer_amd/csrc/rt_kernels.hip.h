@@ -81,24 +81,37 @@ __device__ __forceinline__ rtf::Prim<R> load_prim(const rtf::Prim<R>* p)
     return out;
 }
 
+template <class R, bool TRI_ONLY>
+__device__ __forceinline__ void test_prim(const rtf::Prim<R>& p, const R* o, const R* d, R& dist, int& hit)
+{
+    R t;
+    if (TRI_ONLY) t = rtm::tri_intersect_staged<R>(p.a, p.e1, p.e2, o, d);
+    else t = p.kind == rtf::PRIM_TRI ? rtm::tri_intersect_staged<R>(p.a, p.e1, p.e2, o, d) : rtm::prim_intersect<R>(p, o, d);
+    if (t >= R(0) && t < dist) { dist = t; hit = (int)p.id; }
+}
+
 // Leaf: test every primitive in leaf order, accept iff t >= 0 && t < dist (BVH.cpp:135-149).
-// The next record is fetched while the current one is tested.
+// The next record is fetched while the current one is tested; two register sets take turns so that
+// no record is ever copied from one set to the other.
 template <class R, bool COUNT, bool TRI_ONLY>
 __device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims, uint32_t leaf, const R* o, const R* d, R& dist, int& hit,
                                           WorkCount* wc)
 {
-    uint32_t first = leaf & rtf::LEAF_FIRST_MASK;
-    uint32_t cnt = (leaf >> rtf::LEAF_COUNT_SHIFT) & 15u;
+    const rtf::Prim<R>* p = prims + (leaf & rtf::LEAF_FIRST_MASK);
+    const uint32_t cnt = (leaf >> rtf::LEAF_COUNT_SHIFT) & 15u;
     if (COUNT) wc->prims += cnt;
-    rtf::Prim<R> cur = load_prim<R>(prims + first);
-    for (uint32_t k = 0; k < cnt; k++) {
-        rtf::Prim<R> nxt = cur;
-        if (k + 1 < cnt) nxt = load_prim<R>(prims + first + k + 1);
-        R t;
-        if (TRI_ONLY) t = rtm::tri_intersect_flat<R>(cur.a, cur.e1, cur.e2, o, d);
-        else t = cur.kind == rtf::PRIM_TRI ? rtm::tri_intersect_flat<R>(cur.a, cur.e1, cur.e2, o, d) : rtm::prim_intersect<R>(cur, o, d);
-        if (t >= R(0) && t < dist) { dist = t; hit = (int)cur.id; }
-        cur = nxt;
+    if (cnt == 0) return;
+    // the fetches are unconditional (index clamped to the last record) so that they stay in flight
+    // across the test instead of being waited for at the join of a divergent branch
+    const uint32_t last = cnt - 1;
+    rtf::Prim<R> even = load_prim<R>(p), odd;
+    for (uint32_t k = 0;; k += 2) {
+        odd = load_prim<R>(p + (k + 1 < last ? k + 1 : last));
+        test_prim<R, TRI_ONLY>(even, o, d, dist, hit);
+        if (k + 1 > last) break;
+        even = load_prim<R>(p + (k + 2 < last ? k + 2 : last));
+        test_prim<R, TRI_ONLY>(odd, o, d, dist, hit);
+        if (k + 2 > last) break;
     }
 }
 

@@ -125,6 +125,47 @@ RT_HD R tri_intersect_flat(const R* A, const R* e1, const R* e2, const R* o, con
     return reject ? R(-1) : t;
 }
 
+// The same test arranged for SIMD execution: the reciprocal (a correctly rounded division, by far the
+// most expensive step) is postponed until the signs of the three numerators have been looked at.
+// u = f * x with f = 1 / a is negative exactly when a and x have opposite signs, provided the
+// product cannot underflow to zero; the guards (|a| < BIG, |x| > TINY) ensure |f * x| stays far
+// inside the normal range, and any NaN makes a guard false and falls through to the full
+// computation.  The same holds for v = f * y and t = f * z.  A lane that leaves early returns -1
+// where the reference returns either -1 or a negative t; both are dropped by the caller's
+// `t >= 0`.  Lanes that reach the end compute u, v and t exactly as tri_intersect does.
+template <class R> struct SignGuard;
+template <> struct SignGuard<float> { static constexpr float BIG = 1e15f, TINY = 1e-15f; };
+template <> struct SignGuard<double> { static constexpr double BIG = 1e150, TINY = 1e-150; };
+
+template <class R>
+RT_HD R tri_intersect_staged(const R* A, const R* e1, const R* e2, const R* o, const R* d)
+{
+    R qx = d[1] * e2[2] - d[2] * e2[1];
+    R qy = d[2] * e2[0] - d[0] * e2[2];
+    R qz = d[0] * e2[1] - d[1] * e2[0];
+    R a = e1[0] * qx + e1[1] * qy + e1[2] * qz;
+    R abs_a = rt_abs<R>(a);
+    if (abs_a < R(0.00001)) return R(-1);
+    const bool guarded = abs_a < SignGuard<R>::BIG;
+    const bool a_neg = a < R(0);
+    R sx = o[0] - A[0], sy = o[1] - A[1], sz = o[2] - A[2];
+    R x = sx * qx + sy * qy + sz * qz;
+    if (guarded && rt_abs<R>(x) > SignGuard<R>::TINY && (x < R(0)) != a_neg) return R(-1);   // u < 0
+    R rx = sy * e1[2] - sz * e1[1];
+    R ry = sz * e1[0] - sx * e1[2];
+    R rz = sx * e1[1] - sy * e1[0];
+    R y = d[0] * rx + d[1] * ry + d[2] * rz;
+    if (guarded && rt_abs<R>(y) > SignGuard<R>::TINY && (y < R(0)) != a_neg) return R(-1);   // v < 0
+    R z = rx * e2[0] + ry * e2[1] + rz * e2[2];
+    if (guarded && rt_abs<R>(z) > SignGuard<R>::TINY && (z < R(0)) != a_neg) return R(-1);   // t < 0
+    R f = R(1) / a;
+    R u = f * x;
+    if (u < R(0)) return R(-1);
+    R v = f * y;
+    if (v < R(0) || u + v > R(1)) return R(-1);
+    return f * z;
+}
+
 // Sphere::findIntersection (Sphere.h:44-90): origin pre-offset by 0.1 * dir, and the second root
 // exactly as written there.
 template <class R>
