@@ -38,10 +38,11 @@ open(os.path.join(dst, f"{tag}_pmc.csv"), "w").write("\n".join(lines) + "\n")
 
 traffic = {}
 for k in {k for (k, c) in means}:
-    if ("FETCH_SIZE" in {c for (kk, c) in means if kk == k}) and ", false>" in k or k.endswith("false>"):
+    # the timed instantiation: trace_primary_kernel<R, COUNT = false, ...>
+    if "trace_primary_kernel<double, false" in k or "trace_primary_kernel<float, false" in k:
         prec = "f64" if "<double" in k else "f32"
         fs, ws = means.get((k, "FETCH_SIZE")), means.get((k, "WRITE_SIZE"))
-        if fs is not None and ws is not None and "primary" in k:
+        if fs is not None and ws is not None:
             traffic[prec] = int((2 * fs + ws) * 1024)
 if traffic:
     traffic["_source"] = f"profiles/{tag}_pmc.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch of trace_primary_kernel"
