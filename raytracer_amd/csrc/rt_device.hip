@@ -241,7 +241,7 @@ int rt_context_create(int device, rt_context** out)
     }
     for (auto& ev : ctx->ev)
         if (hipEventCreate(&ev) != hipSuccess) { delete ctx; return fail(RT_ERR_HIP, "hipEventCreate failed"); }
-    int rc = ctx->counters.reserve(1024);
+    int rc = ctx->counters.reserve(std::max<size_t>(1024, sizeof(rtr::RenderCounters)));
     if (rc) { delete ctx; return rc; }
     *out = ctx;
     return RT_OK;
@@ -698,13 +698,15 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     const int rows = a.row_end - a.row_begin;
     const unsigned long long samples = (unsigned long long)a.width * rows * a.aadepth;
     const int levels = std::min(p->tracing_depth, rtr::MAX_LEVELS);
-    // worst case: every hit of a level spawns two (reflection + refraction)
+    // worst case: every hit of a level spawns two (reflection + refraction); the queues are split into
+    // shards of equal capacity that fill nearly evenly (producers pick shards round-robin), with slack
     const unsigned long long cap_hits = samples << std::max(0, std::min(levels - 1, 3));
-    const unsigned long long cap_gq = cap_hits;
+    const unsigned long long shard_cap = (cap_hits + rtq::SHARDS - 1) / rtq::SHARDS + 16384;
+    const unsigned long long cap_total = shard_cap * rtq::SHARDS;
     int rc;
-    if ((rc = ctx->hits_a.reserve(cap_hits * sizeof(rtr::HitRec)))) return rc;
-    if ((rc = ctx->hits_b.reserve(cap_hits * sizeof(rtr::HitRec)))) return rc;
-    if ((rc = ctx->gq.reserve(cap_gq * sizeof(rtg::GatherRec)))) return rc;
+    if ((rc = ctx->hits_a.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
+    if ((rc = ctx->hits_b.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
+    if ((rc = ctx->gq.reserve(cap_total * sizeof(rtg::GatherRec)))) return rc;
     int cap = stack_cap(ctx);
     size_t lds = rtk::stack_lds_bytes(cap, sizeof(R));
     if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
@@ -717,13 +719,13 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     const int64_t tiles = (int64_t)((a.width + 7) / 8) * ((rows + 7) / 8);
     const int waves_per_block = rtk::BLOCK / 64;
     hipLaunchKernelGGL((rtr::render_primary_kernel<R>), dim3((unsigned)((tiles + waves_per_block - 1) / waves_per_block)), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a,
-                       (rtr::HitRec*)ctx->hits_a.p, cap_hits, ctr, cap);
+                       (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap);
     HIP_TRY(hipGetLastError());
     rtr::HitRec* qin = (rtr::HitRec*)ctx->hits_a.p;
     rtr::HitRec* qout = (rtr::HitRec*)ctx->hits_b.p;
     for (int level = 1; level <= levels; level++) {
         hipLaunchKernelGGL((rtr::shade_level_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), sd, a, level,
-                           level == levels ? 1 : 0, qin, qout, cap_hits, (rtg::GatherRec*)ctx->gq.p, cap_gq, ctr, cap);
+                           level == levels ? 1 : 0, qin, qout, shard_cap, (rtg::GatherRec*)ctx->gq.p, ctr, cap);
         HIP_TRY(hipGetLastError());
         std::swap(qin, qout);
     }
@@ -734,7 +736,7 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
         gp.r2 = (float)(p->photon_dist * p->photon_dist);
         gp.norm = (double)(p->photon_num / 16) * 3.1415926;
         hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], (const rtg::GatherRec*)ctx->gq.p,
-                           &ctr->n_gather, &ctr->next_gather, gp, d_acc);
+                           &ctr->gather, shard_cap, &ctr->next_gather, gp, d_acc);
         HIP_TRY(hipGetLastError());
     }
     if (host_ctr) HIP_TRY(hipMemcpyAsync(host_ctr, ctr, sizeof(*host_ctr), hipMemcpyDeviceToHost, ctx->stream));
@@ -802,7 +804,7 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
             if (hc[i].overflow_stack) return fail(RT_ERR_LIMIT, "traversal stack overflow");
             if (hc[i].overflow_queue) return fail(RT_ERR_LIMIT, "bounce/gather queue overflow");
             total.secondary_rays += hc[i].secondary_rays;
-            total.gather_queries += hc[i].n_gather;
+            for (int sh = 0; sh < rtq::SHARDS; sh++) total.gather_queries += hc[i].gather.n[sh][0];
         }
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));

@@ -14,6 +14,8 @@
 // as with the reference's heap); only max d2 and the weighted sum leave the kernel.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include "rt_queue.hip.h"
 #include <stdint.h>
 
 namespace rtg {
@@ -249,36 +251,42 @@ __device__ void estimate(const PhotonMapView& pm, const WaveLds& L, int count, c
     }
 }
 
-// Gather queue consumer: acc[3*pixel..] += weight * clip(estimate)
-__global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const GatherRec* __restrict__ recs, const unsigned long long* n_recs,
-                                                      unsigned long long* next, GatherParams gp, double* __restrict__ acc)
+// Gather queue consumer: acc[3*pixel..] += weight * clip(estimate).  One request per wave at a time.
+// Requests differ a lot in cost, so the (single-wave) blocks of the persistent grid draw them from
+// a shared counter -- several per draw while plenty are left, one near the end; a request takes
+// tens of microseconds, which keeps the draw rate far below what one counter word sustains.
+__global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const GatherRec* __restrict__ recs, const rtq::Counts* cnt,
+                                                      unsigned long long shard_cap, unsigned long long* next, GatherParams gp,
+                                                      double* __restrict__ acc)
 {
     __shared__ WaveLds L;
     const int lane = lane_id();
-    const unsigned long long n = *n_recs;
-    unsigned long long q_begin = 0, q_end = 0;
+    const rtq::Map map = rtq::map_units(cnt, shard_cap, 1);
+    const uint32_t n = map.total;
+    uint32_t q_end = 0;
     while (true) {
-        // several queries per request on the shared counter, fewer near the end (see rtk::next_batch)
-        unsigned long long left = n > q_end ? n - q_end : 0;
-        unsigned long long want = left / (4ull * gridDim.x);
+        uint32_t left = n > q_end ? n - q_end : 0;
+        uint32_t want = left / (4u * gridDim.x);
         want = want < 1 ? 1 : (want > 16 ? 16 : want);
         unsigned long long q0 = 0;
-        if (lane == 0) q0 = atomicAdd(next, want);
+        if (lane == 0) q0 = atomicAdd(next, (unsigned long long)want);
         q0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q0);
         if (q0 >= n) break;
-        q_begin = q0;
-        q_end = q0 + want < n ? q0 + want : n;
-      for (unsigned long long q = q_begin; q < q_end; q++) {
-        const GatherRec& r = recs[q];
-        int count;
-        knn_collect(pm, L, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, count);
-        __builtin_amdgcn_wave_barrier();
-        double rgb[3];
-        float md2;
-        estimate(pm, L, count, r.normal, r.color, gp.norm, rgb, &md2);
-        if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * (lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2])));
-        __builtin_amdgcn_wave_barrier();
-      }
+        q_end = q0 + want < n ? (uint32_t)q0 + want : n;
+        for (uint32_t q = (uint32_t)q0; q < q_end; q++) {
+            unsigned shard;
+            uint32_t first, n_shard;
+            rtq::locate(map, q, 1, shard, first, n_shard);
+            const GatherRec& r = recs[(unsigned long long)shard * shard_cap + first];
+            int count;
+            knn_collect(pm, L, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, count);
+            __builtin_amdgcn_wave_barrier();
+            double rgb[3];
+            float md2;
+            estimate(pm, L, count, r.normal, r.color, gp.norm, rgb, &md2);
+            if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * (lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2])));
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 }
 

@@ -16,6 +16,7 @@
 
 #include "rt_gather.hip.h"
 #include "rt_kernels.hip.h"
+#include "rt_queue.hip.h"
 
 namespace rtr {
 
@@ -34,14 +35,12 @@ struct HitRec {
 };
 
 struct RenderCounters {
-    unsigned long long next_primary;
-    unsigned long long next_level[MAX_LEVELS + 1];
-    unsigned long long next_gather;
-    unsigned long long n_hits[MAX_LEVELS + 2];   // n_hits[d] = queue length of level d (1-based)
-    unsigned long long n_gather;
+    rtq::Counts hits[MAX_LEVELS + 2];   // hits[d] = fill of the bounce queue of level d (1-based)
+    rtq::Counts gather;                 // fill of the gather queue
     unsigned long long overflow_stack, overflow_queue;
     unsigned long long secondary_rays;
-    unsigned long long pad[3];
+    unsigned long long next_gather;     // draw counter of the gather kernel
+    unsigned long long pad[4];
 };
 
 struct ShadeData {
@@ -59,31 +58,8 @@ struct RenderArgs {
     int head_quirk, use_photon_map;
 };
 
-__device__ __forceinline__ unsigned prefix_rank(unsigned long long mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
-
-// wave-aggregated append: one atomic per wave, lanes write at base + rank
-template <class T>
-__device__ __forceinline__ void queue_push(T* q, unsigned long long* n, unsigned long long cap, bool want, const T& rec, unsigned long long* overflow)
-{
-    unsigned long long m = __ballot(want);
-    if (m == 0) return;
-    unsigned long long base = 0;
-    int leader = __builtin_ctzll(m);
-    if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(n, (unsigned long long)__builtin_popcountll(m));
-    unsigned lo = __shfl((unsigned)base, leader), hi = __shfl((unsigned)(base >> 32), leader);
-    base = ((unsigned long long)hi << 32) | lo;
-    if (want) {
-        unsigned long long p = base + prefix_rank(m);
-        if (p < cap) q[p] = rec;
-        else *overflow = 1;
-    }
-}
-
 template <class R>
-__global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits, unsigned long long cap_hits,
+__global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits, unsigned long long shard_cap,
                                                                RenderCounters* ctr, int cap)
 {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -122,7 +98,7 @@ __global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R>
                     want = true;
                 }
             }
-            queue_push(hits, &ctr->n_hits[1], cap_hits, want, rec, &ovf_queue);
+            rtq::push(hits, &ctr->hits[1], shard_cap, want, rec, &ovf_queue);
         }
     }
     if (ovf_stack) atomicMax(&ctr->overflow_stack, 1ull);
@@ -132,27 +108,28 @@ __global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R>
 // One recursion level of getColorAt for every queued hit.
 template <class R>
 __global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv, ShadeData sd, RenderArgs a, int level, int last_level,
-                                                            const HitRec* __restrict__ in, HitRec* __restrict__ out, unsigned long long cap_hits,
-                                                            rtg::GatherRec* __restrict__ gq, unsigned long long cap_gq, RenderCounters* ctr, int cap)
+                                                            const HitRec* __restrict__ in, HitRec* __restrict__ out, unsigned long long shard_cap,
+                                                            rtg::GatherRec* __restrict__ gq, RenderCounters* ctr, int cap)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     LaneStack st = rtk::make_stack<R>(lds, cap);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0, n_secondary = 0;
-    const unsigned long long n_in = ctr->n_hits[level] < cap_hits ? ctr->n_hits[level] : cap_hits;
-    const unsigned long long chunks = (n_in + WAVE - 1) / WAVE;
-    const unsigned n_waves = gridDim.x * (blockDim.x >> 6);
-    // the queue length lives in device memory, so the grid is persistent; chunks are dealt round-robin
-    // to the waves (no work counter: one word serves only ~90 requests per microsecond chip-wide)
-    for (unsigned long long chunk = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); chunk < chunks; chunk += n_waves) {
-        unsigned long long i = chunk * WAVE + st.lane;
-        bool active = i < n_in;
+    // the queue length lives in device memory, so the grid is persistent; chunks of 64 hits are dealt
+    // round-robin to the waves (no shared work counter)
+    const rtq::Map map = rtq::map_units(&ctr->hits[level], shard_cap, WAVE);
+    for (uint32_t chunk = rtq::wave_index(); chunk < map.total; chunk += rtq::n_waves()) {
+        unsigned shard;
+        uint32_t first, n_shard;
+        rtq::locate(map, chunk, WAVE, shard, first, n_shard);
+        const uint32_t i = first + st.lane;
+        bool active = i < n_shard;
         HitRec next[2];
         bool want[2] = {false, false};
         rtg::GatherRec g;
         bool want_g = false;
         if (active) {
-            HitRec rec = in[i];
+            HitRec rec = in[(unsigned long long)shard * shard_cap + i];
             rtm::D3 hit_dir = {rec.dir[0], rec.dir[1], rec.dir[2]};
             rtm::D3 hit_pos = rtm::vadd(rtm::D3{rec.pos[0], rec.pos[1], rec.pos[2]}, rtm::vmul(hit_dir, a.accuracy));   // main.cpp:162
             const rtf::ObjShade& obj = sd.objs[rec.obj];
@@ -223,9 +200,9 @@ __global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv
                 want_g = true;
             }
         }
-        queue_push(out, &ctr->n_hits[level + 1], cap_hits, want[0], next[0], &ovf_queue);
-        queue_push(out, &ctr->n_hits[level + 1], cap_hits, want[1], next[1], &ovf_queue);
-        queue_push(gq, &ctr->n_gather, cap_gq, want_g, g, &ovf_queue);
+        rtq::push(out, &ctr->hits[level + 1], shard_cap, want[0], next[0], &ovf_queue);
+        rtq::push(out, &ctr->hits[level + 1], shard_cap, want[1], next[1], &ovf_queue);
+        rtq::push(gq, &ctr->gather, shard_cap, want_g, g, &ovf_queue);
     }
     if (ovf_stack) atomicMax(&ctr->overflow_stack, 1ull);
     if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
