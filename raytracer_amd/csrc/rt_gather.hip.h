@@ -2,14 +2,21 @@
 // estimate of main.cpp:260-295), one query per wave64.
 //
 // The reference walks a pointer kd-tree keeping a max-heap of k photon pointers.  Here the tree is
-// implicit over one in-order array (see FlatPhotonMap); the whole wave walks it together:
-//   - inner node: the pivot photon is tested, the near side is entered, the far side is pushed
-//     with its squared plane distance and skipped on pop once that exceeds the current bound
-//     (same pruning as Kdtree.cpp:121-132, with the up-to-date bound);
-//   - leaf (<= 64 photons): one photon per lane, coalesced; photons with d2 < bound are appended
-//     to a candidate buffer in LDS through a ballot prefix;
-//   - when the buffer is nearly full, a wave-wide radix select finds the k-th smallest d2, keeps
-//     exactly the k nearest candidates and tightens the bound to that distance.
+// implicit over one in-order array (see FlatPhotonMap: a subtree is a contiguous range, its pivot
+// the middle element, ranges of <= 64 photons are leaves).  A serial walk would pay one dependent
+// memory round trip per tree level and leaf, so the wave works on many subtrees at once:
+//   1. it walks down the near side from the root to the first range of <= 2k photons, testing the
+//      pivots on the way and remembering the far sides; that range is scanned linearly (coalesced,
+//      64 photons per step, several steps in flight), which yields a first bound: the k-th
+//      smallest distance found so far;
+//   2. the remembered far sides form a frontier of ranges in LDS.  Each round the lanes take up
+//      to 64 ranges from its top, drop those whose plane distance exceeds the current bound
+//      (the pruning of Kdtree.cpp:121-132 with the up-to-date bound), test their pivots and put
+//      the children back (far side only if its plane distance is within the bound); ranges that
+//      are leaves are scanned by the whole wave as in step 1;
+//   3. photons with d2 < bound go to a candidate buffer in LDS through a ballot prefix; when it is
+//      nearly full, a wave-wide radix select keeps exactly the k nearest candidates and tightens
+//      the bound to the k-th distance.
 // The result is the exact k-nearest set within the radius (ties at the k-th distance arbitrary,
 // as with the reference's heap); only max d2 and the weighted sum leave the kernel.
 #pragma once
@@ -22,8 +29,10 @@ namespace rtg {
 
 constexpr int WAVE = 64;
 constexpr int CAP = 2048;        // candidate buffer entries per wave
-constexpr int MAX_K = CAP - 2 * WAVE;
+constexpr int GROUP = 4;         // 64-photon steps of a linear scan kept in flight together
+constexpr int MAX_K = CAP - GROUP * WAVE;
 constexpr int STACK = 48;        // > log2(2^31 / 64) levels
+constexpr int FRONT = 256;       // frontier capacity (ranges); beyond it subtrees are walked serially
 
 struct PhotonMapView {
     const float* pos;            // 3 per photon, tree order
@@ -47,7 +56,10 @@ struct WaveLds {
     float key[CAP];
     uint32_t idx[CAP];
     uint32_t hist[256];
-    int s_lo[STACK], s_hi[STACK];
+    int f_lo[FRONT], f_hi[FRONT];   // frontier of pending subtrees: range and squared plane distance
+    float f_d2[FRONT];
+    int c_lo[WAVE], c_n[WAVE];      // steps of the current linear scan: first photon, count (<= 64)
+    int s_lo[STACK], s_hi[STACK];   // stack of the serial walk
     float s_d2[STACK];
 };
 
@@ -140,17 +152,75 @@ __device__ __forceinline__ void append(WaveLds& L, int& count, bool take, float 
     count += __builtin_popcountll(m);
 }
 
-// Walk the implicit tree for one query held identically by all lanes.  On return L.key/L.idx[0..count)
-// is the k-nearest set within sqrt(r2).
-__device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float qy, float qz, int k, float r2, int& count)
+// Make room for `need` more candidates (need <= GROUP * WAVE): if they might not fit, keep the k
+// nearest and tighten the bound.  count > k holds whenever this triggers (k <= MAX_K).
+__device__ __forceinline__ void make_room(WaveLds& L, int& count, int k, float& bound, int need)
+{
+    if (count > CAP - need) {
+        __builtin_amdgcn_wave_barrier();
+        bound = select_k(L, count, k);
+    }
+}
+
+// Linear scan of the n_steps (<= 64) steps listed in L.c_lo / L.c_n, GROUP steps in flight.
+__device__ void scan_steps(const PhotonMapView& pm, WaveLds& L, const float* q, int n_steps, int k, float& bound, int& count)
 {
     const int lane = lane_id();
-    count = 0;
-    if (pm.n <= 0) return;
-    float bound = r2;            // candidates need d2 < bound (Kdtree.cpp:77,82: strict)
-    const float q[3] = {qx, qy, qz};
+    for (int g = 0; g < n_steps; g += GROUP) {
+        float px[GROUP], py[GROUP], pz[GROUP];
+        int id[GROUP];
+        bool valid[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; u++) {
+            valid[u] = false;
+            id[u] = 0;
+            if (g + u < n_steps) {
+                int lo = L.c_lo[g + u], n = L.c_n[g + u];
+                valid[u] = lane < n;
+                id[u] = lo + lane;
+                if (valid[u]) {
+                    const float* p = pm.pos + 3 * (size_t)id[u];
+                    px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+                }
+            }
+        }
+        make_room(L, count, k, bound, GROUP * WAVE);
+#pragma unroll
+        for (int u = 0; u < GROUP; u++) {
+            float d2 = 3.0e38f;
+            if (valid[u]) {
+                float dx = q[0] - px[u], dy = q[1] - py[u], dz = q[2] - pz[u];
+                d2 = dx * dx + dy * dy + dz * dz;
+            }
+            append(L, count, valid[u] && d2 < bound, d2, (uint32_t)id[u]);
+        }
+    }
+}
+
+// Linear scan of one contiguous range (a whole subtree), any length.
+__device__ void scan_range(const PhotonMapView& pm, WaveLds& L, const float* q, int lo, int hi, int k, float& bound, int& count)
+{
+    const int lane = lane_id();
+    while (lo < hi) {
+        int steps = (hi - lo + WAVE - 1) / WAVE;
+        if (steps > WAVE) steps = WAVE;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < steps) {
+            int first = lo + lane * WAVE;
+            L.c_lo[lane] = first;
+            L.c_n[lane] = hi - first < WAVE ? hi - first : WAVE;
+        }
+        __builtin_amdgcn_wave_barrier();
+        scan_steps(pm, L, q, steps, k, bound, count);
+        lo += steps * WAVE;
+    }
+}
+
+// Serial depth-first walk of one subtree (all lanes in step); used when the frontier is full.
+__device__ void walk_serial(const PhotonMapView& pm, WaveLds& L, const float* q, int lo, int hi, int k, float& bound, int& count)
+{
+    const int lane = lane_id();
     int sp = 0;
-    int lo = 0, hi = (int)pm.n;
     float dfar = 0.f;
     bool have = true;
     while (true) {
@@ -165,8 +235,9 @@ __device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float
             int mid = lo + (hi - lo) / 2;
             int ax = pm.axis[mid];
             float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
-            float dx = qx - px, dy = qy - py, dz = qz - pz;
+            float dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
             float d2 = dx * dx + dy * dy + dz * dz;
+            make_room(L, count, k, bound, WAVE);
             append(L, count, lane == 0 && d2 < bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119)
             float split = ax == 0 ? px : (ax == 1 ? py : pz);
             float delta = q[ax] - split;
@@ -180,20 +251,116 @@ __device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float
             }
             lo = nlo; hi = nhi;
         }
-        {   // leaf: one photon per lane
-            int i = lo + lane;
-            bool valid = i < hi;
-            float d2 = 3.0e38f;
-            if (valid) {
-                float dx = qx - pm.pos[3 * (size_t)i], dy = qy - pm.pos[3 * (size_t)i + 1], dz = qz - pm.pos[3 * (size_t)i + 2];
-                d2 = dx * dx + dy * dy + dz * dz;
-            }
-            append(L, count, valid && d2 < bound, d2, (uint32_t)i);
+        scan_range(pm, L, q, lo, hi, k, bound, count);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// k nearest photons within sqrt(r2) of one query held identically by all lanes.  On return
+// L.key/L.idx[0..count) is the set.
+__device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float qy, float qz, int k, float r2, int& count)
+{
+    const int lane = lane_id();
+    count = 0;
+    if (pm.n <= 0) return;
+    float bound = r2;            // candidates need d2 < bound (Kdtree.cpp:77,82: strict)
+    const float q[3] = {qx, qy, qz};
+
+    // ---- 1. near side down to a range of <= 2k photons, far sides onto the frontier
+    int nf = 0;
+    int lo = 0, hi = (int)pm.n;
+    const int limit = 2 * k > WAVE ? 2 * k : WAVE;
+    while (hi - lo > limit) {
+        int mid = lo + (hi - lo) / 2;
+        int ax = pm.axis[mid];
+        float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
+        float dx = qx - px, dy = qy - py, dz = qz - pz;
+        float d2 = dx * dx + dy * dy + dz * dz;
+        append(L, count, lane == 0 && d2 < bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119); < 32 of these
+        float split = ax == 0 ? px : (ax == 1 ? py : pz);
+        float delta = q[ax] - split;
+        int nlo, nhi, flo, fhi;
+        if (delta < 0.f) { nlo = lo; nhi = mid; flo = mid + 1; fhi = hi; }      // Kdtree.cpp:121
+        else { nlo = mid + 1; nhi = hi; flo = lo; fhi = mid; }
+        float dd = delta * delta;
+        if (fhi > flo && dd <= bound) {          // at most one per level: nf < 32 <= FRONT
+            if (lane == 0) { L.f_lo[nf] = flo; L.f_hi[nf] = fhi; L.f_d2[nf] = dd; }
+            nf++;
+        }
+        lo = nlo; hi = nhi;
+    }
+    scan_range(pm, L, q, lo, hi, k, bound, count);
+    if (count > k) {
+        __builtin_amdgcn_wave_barrier();
+        bound = select_k(L, count, k);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- 2. frontier rounds
+    while (nf > 0) {
+        const int take = nf < WAVE ? nf : WAVE;
+        const int base = nf - take;
+        nf = base;
+        int rlo = 0, rhi = 0;
+        float rd2 = 0.f;
+        if (lane < take) { rlo = L.f_lo[base + lane]; rhi = L.f_hi[base + lane]; rd2 = L.f_d2[base + lane]; }
+        const bool live = lane < take && rhi > rlo && !(rd2 > bound);
+        const bool is_leaf = live && rhi - rlo <= WAVE;
+        const bool is_inner = live && !is_leaf;
+        int mid = 0, nlo = 0, nhi = 0, flo = 0, fhi = 0;
+        float dd = 0.f, d2 = 3.0e38f;
+        if (is_inner) {
+            mid = rlo + (rhi - rlo) / 2;
+            int ax = pm.axis[mid];
+            float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
+            float dx = qx - px, dy = qy - py, dz = qz - pz;
+            d2 = dx * dx + dy * dy + dz * dz;
+            float split = ax == 0 ? px : (ax == 1 ? py : pz);
+            float delta = (ax == 0 ? qx : (ax == 1 ? qy : qz)) - split;
+            if (delta < 0.f) { nlo = rlo; nhi = mid; flo = mid + 1; fhi = rhi; }
+            else { nlo = mid + 1; nhi = rhi; flo = rlo; fhi = mid; }
+            dd = delta * delta;
+        }
+        make_room(L, count, k, bound, WAVE);
+        append(L, count, is_inner && d2 < bound, d2, (uint32_t)mid);
+        const bool push_far = is_inner && fhi > flo && dd <= bound;
+        const bool push_near = is_inner && nhi > nlo;
+        const unsigned long long m_far = __ballot(push_far), m_near = __ballot(push_near), m_leaf = __ballot(is_leaf);
+        const int n_far = __builtin_popcountll(m_far), n_near = __builtin_popcountll(m_near), n_leaf = __builtin_popcountll(m_leaf);
+        __builtin_amdgcn_wave_barrier();
+        if (is_leaf) {
+            int r = (int)prefix_rank(m_leaf);
+            L.c_lo[r] = rlo;
+            L.c_n[r] = rhi - rlo;
+        }
+        const bool fits = nf + n_far + n_near <= FRONT;
+        if (fits) {
+            // far sides below near sides: the near sides are taken first
+            if (push_far) { int p = nf + (int)prefix_rank(m_far); L.f_lo[p] = flo; L.f_hi[p] = fhi; L.f_d2[p] = dd; }
+            nf += n_far;
+            if (push_near) { int p = nf + (int)prefix_rank(m_near); L.f_lo[p] = nlo; L.f_hi[p] = nhi; L.f_d2[p] = 0.f; }
+            nf += n_near;
         }
         __builtin_amdgcn_wave_barrier();
-        if (count > CAP - 2 * WAVE) bound = select_k(L, count, k);
+        scan_steps(pm, L, q, n_leaf, k, bound, count);
+        if (!fits) {
+            // frontier full: walk this round's children serially instead, lane by lane
+            unsigned long long todo = m_far | m_near;
+            while (todo) {
+                int src = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                int a_lo = __shfl(nlo, src), a_hi = __shfl(nhi, src), b_lo = __shfl(flo, src), b_hi = __shfl(fhi, src);
+                float b_dd = __shfl(dd, src);
+                if ((m_near >> src) & 1ull) walk_serial(pm, L, q, a_lo, a_hi, k, bound, count);
+                if (((m_far >> src) & 1ull) && !(b_dd > bound)) walk_serial(pm, L, q, b_lo, b_hi, k, bound, count);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
-    if (count > k) select_k(L, count, k);
+    if (count > k) {
+        __builtin_amdgcn_wave_barrier();
+        select_k(L, count, k);
+    }
 }
 
 struct GatherParams {
