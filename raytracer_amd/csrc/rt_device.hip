@@ -648,10 +648,23 @@ int knn_launch(rt_context* ctx, int which, int k, double max_dist, int photon_nu
     gp.r2 = (float)(max_dist * max_dist);
     gp.norm = (double)(photon_num / 16) * 3.1415926;            // PHOTONMUM/16*PI, integer division first (main.cpp:293)
     int blocks = (int)std::min<int64_t>(n, (int64_t)ctx->num_cus * 8);
+    // RT_GATHER_PROF=1: per-phase cycle totals of the gather, printed to stderr (development aid)
+    const bool prof = getenv("RT_GATHER_PROF") != nullptr;
+    unsigned long long* d_prof = prof ? (unsigned long long*)ctx->counters.p + 8 : nullptr;
+    if (prof) HIP_TRY(hipMemsetAsync(d_prof, 0, rtg::P_SLOTS * 8, ctx->stream));
     hipLaunchKernelGGL(rtg::knn_batch_kernel, dim3(blocks), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[which], (long long)n, d_pos,
                        nrm ? d_nrm : nullptr, col ? d_col : nullptr, gp, (int*)ctx->st_ids.p, (double*)ctx->st_dist.p, rgb ? d_rgb : nullptr,
-                       idx ? (int*)ctx->st_aux.p : nullptr, (unsigned long long*)ctx->counters.p);
+                       idx ? (int*)ctx->st_aux.p : nullptr, (unsigned long long*)ctx->counters.p, d_prof);
     HIP_TRY(hipGetLastError());
+    if (prof) {
+        unsigned long long v[rtg::P_SLOTS];
+        HIP_TRY(hipMemcpyAsync(v, d_prof, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        double nq = (double)std::max<unsigned long long>(1, v[rtg::P_QUERIES]);
+        fprintf(stderr, "gather cycles/query (k=%d): descent %.0f, first scan %.0f, select %.0f (%.2f calls), rounds %.0f (%.1f), leaves %.0f (%.1f), estimate %.0f\n",
+                k, v[rtg::P_DESCENT] / nq, v[rtg::P_SCAN0] / nq, v[rtg::P_SELECT] / nq, v[rtg::P_N_SELECT] / nq, v[rtg::P_ROUNDS] / nq,
+                v[rtg::P_N_ROUNDS] / nq, v[rtg::P_LEAVES] / nq, v[rtg::P_N_LEAVES] / nq, v[rtg::P_ESTIMATE] / nq);
+    }
     if (counts) HIP_TRY(hipMemcpyAsync(counts, ctx->st_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (r2) HIP_TRY(hipMemcpyAsync(r2, ctx->st_dist.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (rgb) HIP_TRY(hipMemcpyAsync(rgb, d_rgb, b3, hipMemcpyDeviceToHost, ctx->stream));

@@ -29,7 +29,8 @@ namespace rtg {
 
 constexpr int WAVE = 64;
 constexpr int CAP = 2048;        // candidate buffer entries per wave
-constexpr int GROUP = 4;         // 64-photon steps of a linear scan kept in flight together
+constexpr int GROUP = 4;         // 64-photon steps of a linear scan between two checks for buffer room
+constexpr int FLIGHT = 16;       // 64-photon steps of a linear scan whose loads are in flight together
 constexpr int MAX_K = CAP - GROUP * WAVE;
 constexpr int STACK = 48;        // > log2(2^31 / 64) levels
 constexpr int FRONT = 256;       // frontier capacity (ranges); beyond it subtrees are walked serially
@@ -52,6 +53,11 @@ struct GatherRec {
     uint32_t pad;
 };
 
+// Optional cycle accounting (development aid): slots of the array a kernel is given.
+enum ProfSlot { P_DESCENT, P_SCAN0, P_SELECT, P_N_SELECT, P_ROUNDS, P_N_ROUNDS, P_LEAVES, P_N_LEAVES, P_ESTIMATE, P_QUERIES, P_SLOTS };
+
+// Per-wave working set in LDS.  The gather kernels run one wave per block, so one file-scope
+// instance serves; helper functions that are not inlined address it directly.
 struct WaveLds {
     float key[CAP];
     uint32_t idx[CAP];
@@ -61,6 +67,22 @@ struct WaveLds {
     int c_lo[WAVE], c_n[WAVE];      // steps of the current linear scan: first photon, count (<= 64)
     int s_lo[STACK], s_hi[STACK];   // stack of the serial walk
     float s_d2[STACK];
+    unsigned long long prof[P_SLOTS];
+};
+__shared__ WaveLds g_L;
+
+struct Prof {
+    unsigned long long* out;     // null: no accounting
+    __device__ void init() const { if (out && (threadIdx.x & 63) < P_SLOTS) g_L.prof[threadIdx.x & 63] = 0; }
+    __device__ void add(int slot, unsigned long long x) const { if (out && (threadIdx.x & 63) == 0) g_L.prof[slot] += x; }
+    __device__ unsigned long long now() const { return out ? (unsigned long long)clock64() : 0ull; }
+    __device__ void flush() const { if (out && (threadIdx.x & 63) < P_SLOTS) atomicAdd(&out[threadIdx.x & 63], g_L.prof[threadIdx.x & 63]); }
+};
+
+// candidate-set state carried through the helpers by value
+struct Cand {
+    int count;       // entries in g_L.key / g_L.idx
+    float bound;     // candidates need d2 < bound
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -73,11 +95,45 @@ __device__ __forceinline__ unsigned prefix_rank(unsigned long long mask)
 // k-th smallest (1-based) of key[0..count): wave-wide MSB-first radix select on the float bits
 // (all keys are non-negative, so the unsigned bit pattern orders like the value).  Afterwards the
 // buffer holds exactly the k smallest entries.  Returns the k-th key.
-__device__ float select_k(WaveLds& L, int& count, int k)
+// Find the owner of the `want`-th element in a 256-bin histogram held in L.hist: returns the bin,
+// the number of elements in lower bins and the bin's own count.  All lanes get the same values.
+__device__ __forceinline__ void locate_bin(uint32_t want, uint32_t& bin, uint32_t& below, uint32_t& in_bin)
 {
+    const WaveLds& L = g_L;
+    const int lane = lane_id();
+    // lane l owns bins 4l .. 4l+3
+    uint32_t h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2], h3 = L.hist[4 * lane + 3];
+    uint32_t s = h0 + h1 + h2 + h3;
+    uint32_t incl = s;
+    for (int off = 1; off < WAVE; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    uint32_t excl = incl - s;
+    bool mine = want > excl && want <= incl;   // exactly one lane
+    uint32_t b = 0, bl = 0, ib = 0;
+    if (mine) {
+        uint32_t w = want - excl;
+        if (w <= h0) { b = 0; bl = excl; ib = h0; }
+        else if (w <= h0 + h1) { b = 1; bl = excl + h0; ib = h1; }
+        else if (w <= h0 + h1 + h2) { b = 2; bl = excl + h0 + h1; ib = h2; }
+        else { b = 3; bl = excl + h0 + h1 + h2; ib = h3; }
+        b += 4 * lane;
+    }
+    int src = __builtin_ctzll(__ballot(mine));
+    bin = __shfl(b, src);
+    below = __shfl(bl, src);
+    in_bin = __shfl(ib, src);
+}
+
+// Bit pattern of the k-th smallest key by most-significant-digit radix passes (any key distribution).
+// `want` returns how many entries equal to it belong to the k smallest.
+__device__ uint32_t radix_threshold(int count, int k, int& want)
+{
+    WaveLds& L = g_L;
     const int lane = lane_id();
     uint32_t prefix = 0, pmask = 0;
-    int want = k;
+    want = k;
     for (int pass = 3; pass >= 0; pass--) {
         for (int b = lane; b < 256; b += WAVE) L.hist[b] = 0;
         __builtin_amdgcn_wave_barrier();
@@ -86,63 +142,124 @@ __device__ float select_k(WaveLds& L, int& count, int k)
             if ((u & pmask) == prefix) atomicAdd(&L.hist[(u >> (8 * pass)) & 255u], 1u);
         }
         __builtin_amdgcn_wave_barrier();
-        // lane l owns bins 4l .. 4l+3
-        uint32_t h0 = L.hist[4 * lane], h1 = L.hist[4 * lane + 1], h2 = L.hist[4 * lane + 2], h3 = L.hist[4 * lane + 3];
-        uint32_t s = h0 + h1 + h2 + h3;
-        uint32_t incl = s;
-        for (int off = 1; off < WAVE; off <<= 1) {
-            uint32_t v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        uint32_t excl = incl - s;
-        bool mine = (uint32_t)want > excl && (uint32_t)want <= incl;   // exactly one lane
-        uint32_t bin = 0, below = 0;
-        if (mine) {
-            uint32_t w = (uint32_t)want - excl;
-            if (w <= h0) { bin = 0; below = excl; }
-            else if (w <= h0 + h1) { bin = 1; below = excl + h0; }
-            else if (w <= h0 + h1 + h2) { bin = 2; below = excl + h0 + h1; }
-            else { bin = 3; below = excl + h0 + h1 + h2; }
-            bin += 4 * lane;
-        }
-        unsigned long long who = __ballot(mine);
-        int src = __builtin_ctzll(who);
-        bin = __shfl(bin, src);
-        below = __shfl(below, src);
+        uint32_t bin, below, in_bin;
+        locate_bin((uint32_t)want, bin, below, in_bin);
         want -= (int)below;
         prefix |= bin << (8 * pass);
         pmask |= 255u << (8 * pass);
         __builtin_amdgcn_wave_barrier();
     }
-    const uint32_t T = prefix;     // bit pattern of the k-th smallest key; `want` = how many == T to keep
-    // stable in-place compaction, one 64-entry chunk at a time (outputs never pass the read cursor)
-    int out = 0, eq_taken = 0;
-    for (int base = 0; base < count; base += WAVE) {
-        int j = base + lane;
-        bool valid = j < count;
-        uint32_t u = valid ? __float_as_uint(L.key[j]) : 0xFFFFFFFFu;
-        uint32_t id = valid ? L.idx[j] : 0u;
-        bool less = valid && u < T;
-        bool eq = valid && u == T;
-        unsigned long long meq = __ballot(eq);
-        bool keep = less || (eq && (eq_taken + (int)prefix_rank(meq)) < want);
-        unsigned long long mk = __ballot(keep);
-        __builtin_amdgcn_wave_barrier();
-        if (keep) {
-            int p = out + (int)prefix_rank(mk);
-            L.key[p] = __uint_as_float(u);
-            L.idx[p] = id;
-        }
-        out += __builtin_popcountll(mk);
-        eq_taken += __builtin_popcountll(meq);
-        __builtin_amdgcn_wave_barrier();
-    }
-    count = out;
-    return __uint_as_float(T);
+    return prefix;
 }
 
-__device__ __forceinline__ void append(WaveLds& L, int& count, bool take, float d2, uint32_t id)
+// Keep the k smallest of L.key[0..count) (count > k).  Squared distances of points spread over a
+// surface are nearly uniformly distributed, so one histogram with 256 bins linear in the key value
+// leaves only a handful of entries in the bin that holds the k-th smallest; those are ranked
+// directly.  (Bins are monotonic in the key, so every entry of a lower bin is smaller.)  Crowded
+// bins -- many equal keys -- fall back to the radix passes.  Returns the k-th key.
+__device__ __attribute__((noinline)) Cand select_k(int count, int k)
 {
+    WaveLds& L = g_L;
+    const int lane = lane_id();
+    // every pass reads UNR x 64 keys before using them, so the LDS latency is paid once per 512 entries
+    constexpr int UNR = 8;
+    float mx = 0.f;
+    for (int base = 0; base < count; base += UNR * WAVE) {
+        float kv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) { int j = base + u * WAVE + lane; kv[u] = j < count ? L.key[j] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) mx = fmaxf(mx, kv[u]);
+    }
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float scale = mx > 0.f ? 255.5f / mx : 0.f;
+    for (int b = lane; b < 256; b += WAVE) L.hist[b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (int base = 0; base < count; base += UNR * WAVE) {
+        float kv[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) { int j = base + u * WAVE + lane; kv[u] = j < count ? L.key[j] : -1.f; }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (kv[u] >= 0.f) {
+                int b = (int)(kv[u] * scale);
+                atomicAdd(&L.hist[b > 255 ? 255 : b], 1u);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t bin, below, in_bin;
+    locate_bin((uint32_t)k, bin, below, in_bin);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t T;
+    int want;
+    if (in_bin <= (uint32_t)WAVE) {
+        // the bin's entries, in buffer order, into L.hist (its counts are no longer needed)
+        int m = 0;
+        for (int base = 0; base < count; base += UNR * WAVE) {
+            float kv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) { int j = base + u * WAVE + lane; kv[u] = j < count ? L.key[j] : -1.f; }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) {
+                int b = (int)(kv[u] * scale);
+                bool hit = kv[u] >= 0.f && (b > 255 ? 255 : b) == (int)bin;
+                unsigned long long mh = __ballot(hit);
+                if (hit) L.hist[m + (int)prefix_rank(mh)] = __float_as_uint(kv[u]);
+                m += __builtin_popcountll(mh);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t e = lane < m ? L.hist[lane] : 0xFFFFFFFFu;
+        int rank = 0;
+        for (int j = 0; j < m; j++) {
+            uint32_t kj = L.hist[j];
+            rank += (kj < e || (kj == e && j < lane)) ? 1 : 0;
+        }
+        const int need = k - (int)below;            // 1-based position of the k-th smallest inside the bin
+        int src = __builtin_ctzll(__ballot(lane < m && rank == need - 1));
+        T = __shfl(e, src);
+        want = __builtin_popcountll(__ballot(lane < m && e == T && rank < need));
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        T = radix_threshold(count, k, want);
+    }
+    // T = bit pattern of the k-th smallest key; `want` = how many entries equal to T to keep
+    // stable in-place compaction (outputs never pass the read cursor: a block of entries is in registers
+    // before any of its outputs is written)
+    int out = 0, eq_taken = 0;
+    for (int base = 0; base < count; base += UNR * WAVE) {
+        uint32_t ku[UNR], id[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            int j = base + u * WAVE + lane;
+            ku[u] = j < count ? __float_as_uint(L.key[j]) : 0xFFFFFFFFu;   // larger than any key: never kept
+            id[u] = j < count ? L.idx[j] : 0u;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            bool less = ku[u] < T;
+            bool eq = ku[u] == T;
+            unsigned long long meq = __ballot(eq);
+            bool keep = less || (eq && (eq_taken + (int)prefix_rank(meq)) < want);
+            unsigned long long mk = __ballot(keep);
+            if (keep) {
+                int p = out + (int)prefix_rank(mk);
+                L.key[p] = __uint_as_float(ku[u]);
+                L.idx[p] = id[u];
+            }
+            out += __builtin_popcountll(mk);
+            eq_taken += __builtin_popcountll(meq);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return Cand{out, __uint_as_float(T)};
+}
+
+__device__ __forceinline__ void append(int& count, bool take, float d2, uint32_t id)
+{
+    WaveLds& L = g_L;
     unsigned long long m = __ballot(take);
     if (take) {
         int p = count + (int)prefix_rank(m);
@@ -154,24 +271,32 @@ __device__ __forceinline__ void append(WaveLds& L, int& count, bool take, float 
 
 // Make room for `need` more candidates (need <= GROUP * WAVE): if they might not fit, keep the k
 // nearest and tighten the bound.  count > k holds whenever this triggers (k <= MAX_K).
-__device__ __forceinline__ void make_room(WaveLds& L, int& count, int k, float& bound, int need)
+__device__ __forceinline__ void make_room(Cand& c, int k, int need, Prof pf)
 {
-    if (count > CAP - need) {
+    // also once the set has grown to twice k (small k): an early, cheap select tightens the bound
+    // long before the buffer fills
+    const int early = k + (k > GROUP * WAVE ? k : GROUP * WAVE);
+    if (c.count > CAP - need || c.count > early) {
         __builtin_amdgcn_wave_barrier();
-        bound = select_k(L, count, k);
+        unsigned long long t = pf.now();
+        c = select_k(c.count, k);
+        pf.add(P_SELECT, pf.now() - t); pf.add(P_N_SELECT, 1);
     }
 }
 
-// Linear scan of the n_steps (<= 64) steps listed in L.c_lo / L.c_n, GROUP steps in flight.
-__device__ void scan_steps(const PhotonMapView& pm, WaveLds& L, const float* q, int n_steps, int k, float& bound, int& count)
+// Linear scan of the n_steps (<= 64) steps listed in L.c_lo / L.c_n.  The loads of FLIGHT steps are
+// issued together (one memory round trip per FLIGHT x 64 photons); room in the candidate buffer is
+// checked before every GROUP steps.
+__device__ __attribute__((noinline)) Cand scan_steps(PhotonMapView pm, float qx, float qy, float qz, int n_steps, int k, Cand c, Prof pf)
 {
+    const WaveLds& L = g_L;
     const int lane = lane_id();
-    for (int g = 0; g < n_steps; g += GROUP) {
-        float px[GROUP], py[GROUP], pz[GROUP];
-        int id[GROUP];
-        bool valid[GROUP];
+    for (int g = 0; g < n_steps; g += FLIGHT) {
+        float px[FLIGHT], py[FLIGHT], pz[FLIGHT];
+        int id[FLIGHT];
+        bool valid[FLIGHT];
 #pragma unroll
-        for (int u = 0; u < GROUP; u++) {
+        for (int u = 0; u < FLIGHT; u++) {
             valid[u] = false;
             id[u] = 0;
             if (g + u < n_steps) {
@@ -184,22 +309,30 @@ __device__ void scan_steps(const PhotonMapView& pm, WaveLds& L, const float* q, 
                 }
             }
         }
-        make_room(L, count, k, bound, GROUP * WAVE);
 #pragma unroll
-        for (int u = 0; u < GROUP; u++) {
-            float d2 = 3.0e38f;
-            if (valid[u]) {
-                float dx = q[0] - px[u], dy = q[1] - py[u], dz = q[2] - pz[u];
-                d2 = dx * dx + dy * dy + dz * dz;
+        for (int v = 0; v < FLIGHT; v += GROUP) {
+            if (g + v < n_steps) {
+                make_room(c, k, GROUP * WAVE, pf);
+#pragma unroll
+                for (int w = 0; w < GROUP; w++) {
+                    const int u = v + w;
+                    float d2 = 3.0e38f;
+                    if (valid[u]) {
+                        float dx = qx - px[u], dy = qy - py[u], dz = qz - pz[u];
+                        d2 = dx * dx + dy * dy + dz * dz;
+                    }
+                    append(c.count, valid[u] && d2 < c.bound, d2, (uint32_t)id[u]);
+                }
             }
-            append(L, count, valid[u] && d2 < bound, d2, (uint32_t)id[u]);
         }
     }
+    return c;
 }
 
 // Linear scan of one contiguous range (a whole subtree), any length.
-__device__ void scan_range(const PhotonMapView& pm, WaveLds& L, const float* q, int lo, int hi, int k, float& bound, int& count)
+__device__ __forceinline__ Cand scan_range(const PhotonMapView& pm, float qx, float qy, float qz, int lo, int hi, int k, Cand c, Prof pf)
 {
+    WaveLds& L = g_L;
     const int lane = lane_id();
     while (lo < hi) {
         int steps = (hi - lo + WAVE - 1) / WAVE;
@@ -211,14 +344,16 @@ __device__ void scan_range(const PhotonMapView& pm, WaveLds& L, const float* q, 
             L.c_n[lane] = hi - first < WAVE ? hi - first : WAVE;
         }
         __builtin_amdgcn_wave_barrier();
-        scan_steps(pm, L, q, steps, k, bound, count);
+        c = scan_steps(pm, qx, qy, qz, steps, k, c, pf);
         lo += steps * WAVE;
     }
+    return c;
 }
 
 // Serial depth-first walk of one subtree (all lanes in step); used when the frontier is full.
-__device__ void walk_serial(const PhotonMapView& pm, WaveLds& L, const float* q, int lo, int hi, int k, float& bound, int& count)
+__device__ __attribute__((noinline)) Cand walk_serial(PhotonMapView pm, float qx, float qy, float qz, int lo, int hi, int k, Cand c, Prof pf)
 {
+    WaveLds& L = g_L;
     const int lane = lane_id();
     int sp = 0;
     float dfar = 0.f;
@@ -228,47 +363,48 @@ __device__ void walk_serial(const PhotonMapView& pm, WaveLds& L, const float* q,
             if (sp == 0) break;
             sp--;
             lo = L.s_lo[sp]; hi = L.s_hi[sp]; dfar = L.s_d2[sp];
-            if (dfar > bound) continue;          // Kdtree.cpp:123-125: far side only if delta^2 <= bound
+            if (dfar > c.bound) continue;          // Kdtree.cpp:123-125: far side only if delta^2 <= bound
         }
         have = false;
         while (hi - lo > WAVE) {
             int mid = lo + (hi - lo) / 2;
             int ax = pm.axis[mid];
             float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
-            float dx = q[0] - px, dy = q[1] - py, dz = q[2] - pz;
+            float dx = qx - px, dy = qy - py, dz = qz - pz;
             float d2 = dx * dx + dy * dy + dz * dz;
-            make_room(L, count, k, bound, WAVE);
-            append(L, count, lane == 0 && d2 < bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119)
+            make_room(c, k, WAVE, pf);
+            append(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119)
             float split = ax == 0 ? px : (ax == 1 ? py : pz);
-            float delta = q[ax] - split;
+            float delta = (ax == 0 ? qx : (ax == 1 ? qy : qz)) - split;
             int nlo, nhi, flo, fhi;
             if (delta < 0.f) { nlo = lo; nhi = mid; flo = mid + 1; fhi = hi; }      // Kdtree.cpp:121
             else { nlo = mid + 1; nhi = hi; flo = lo; fhi = mid; }
             float dd = delta * delta;
-            if (fhi > flo && dd <= bound && sp < STACK) {
+            if (fhi > flo && dd <= c.bound && sp < STACK) {
                 if (lane == 0) { L.s_lo[sp] = flo; L.s_hi[sp] = fhi; L.s_d2[sp] = dd; }
                 sp++;
             }
             lo = nlo; hi = nhi;
         }
-        scan_range(pm, L, q, lo, hi, k, bound, count);
+        c = scan_range(pm, qx, qy, qz, lo, hi, k, c, pf);
         __builtin_amdgcn_wave_barrier();
     }
+    return c;
 }
 
-// k nearest photons within sqrt(r2) of one query held identically by all lanes.  On return
-// L.key/L.idx[0..count) is the set.
-__device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float qy, float qz, int k, float r2, int& count)
+// k nearest photons within sqrt(r2) of one query held identically by all lanes.  Returns the
+// number of photons found; g_L.key / g_L.idx[0..count) is the set.
+__device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, Prof pf)
 {
+    WaveLds& L = g_L;
     const int lane = lane_id();
-    count = 0;
-    if (pm.n <= 0) return;
-    float bound = r2;            // candidates need d2 < bound (Kdtree.cpp:77,82: strict)
-    const float q[3] = {qx, qy, qz};
+    if (pm.n <= 0) return 0;
+    Cand c{0, r2};               // candidates need d2 < bound (Kdtree.cpp:77,82: strict)
 
     // ---- 1. near side down to a range of <= 2k photons, far sides onto the frontier
     int nf = 0;
     int lo = 0, hi = (int)pm.n;
+    unsigned long long t0 = pf.now();
     const int limit = 2 * k > WAVE ? 2 * k : WAVE;
     while (hi - lo > limit) {
         int mid = lo + (hi - lo) / 2;
@@ -276,35 +412,42 @@ __device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float
         float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
         float dx = qx - px, dy = qy - py, dz = qz - pz;
         float d2 = dx * dx + dy * dy + dz * dz;
-        append(L, count, lane == 0 && d2 < bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119); < 32 of these
+        append(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119); < 32 of these
         float split = ax == 0 ? px : (ax == 1 ? py : pz);
-        float delta = q[ax] - split;
+        float delta = (ax == 0 ? qx : (ax == 1 ? qy : qz)) - split;
         int nlo, nhi, flo, fhi;
         if (delta < 0.f) { nlo = lo; nhi = mid; flo = mid + 1; fhi = hi; }      // Kdtree.cpp:121
         else { nlo = mid + 1; nhi = hi; flo = lo; fhi = mid; }
         float dd = delta * delta;
-        if (fhi > flo && dd <= bound) {          // at most one per level: nf < 32 <= FRONT
+        if (fhi > flo && dd <= c.bound) {          // at most one per level: nf < 32 <= FRONT
             if (lane == 0) { L.f_lo[nf] = flo; L.f_hi[nf] = fhi; L.f_d2[nf] = dd; }
             nf++;
         }
         lo = nlo; hi = nhi;
     }
-    scan_range(pm, L, q, lo, hi, k, bound, count);
-    if (count > k) {
+    unsigned long long t1 = pf.now();
+    pf.add(P_DESCENT, t1 - t0);
+    c = scan_range(pm, qx, qy, qz, lo, hi, k, c, pf);
+    t0 = pf.now();
+    pf.add(P_SCAN0, t0 - t1);
+    if (c.count > k) {
         __builtin_amdgcn_wave_barrier();
-        bound = select_k(L, count, k);
+        c = select_k(c.count, k);
+        t1 = pf.now();
+        pf.add(P_SELECT, t1 - t0); pf.add(P_N_SELECT, 1);
     }
     __builtin_amdgcn_wave_barrier();
 
     // ---- 2. frontier rounds
     while (nf > 0) {
+        t0 = pf.now();
         const int take = nf < WAVE ? nf : WAVE;
         const int base = nf - take;
         nf = base;
         int rlo = 0, rhi = 0;
         float rd2 = 0.f;
         if (lane < take) { rlo = L.f_lo[base + lane]; rhi = L.f_hi[base + lane]; rd2 = L.f_d2[base + lane]; }
-        const bool live = lane < take && rhi > rlo && !(rd2 > bound);
+        const bool live = lane < take && rhi > rlo && !(rd2 > c.bound);
         const bool is_leaf = live && rhi - rlo <= WAVE;
         const bool is_inner = live && !is_leaf;
         int mid = 0, nlo = 0, nhi = 0, flo = 0, fhi = 0;
@@ -321,9 +464,9 @@ __device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float
             else { nlo = mid + 1; nhi = rhi; flo = rlo; fhi = mid; }
             dd = delta * delta;
         }
-        make_room(L, count, k, bound, WAVE);
-        append(L, count, is_inner && d2 < bound, d2, (uint32_t)mid);
-        const bool push_far = is_inner && fhi > flo && dd <= bound;
+        make_room(c, k, WAVE, pf);
+        append(c.count, is_inner && d2 < c.bound, d2, (uint32_t)mid);
+        const bool push_far = is_inner && fhi > flo && dd <= c.bound;
         const bool push_near = is_inner && nhi > nlo;
         const unsigned long long m_far = __ballot(push_far), m_near = __ballot(push_near), m_leaf = __ballot(is_leaf);
         const int n_far = __builtin_popcountll(m_far), n_near = __builtin_popcountll(m_near), n_leaf = __builtin_popcountll(m_leaf);
@@ -342,7 +485,10 @@ __device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float
             nf += n_near;
         }
         __builtin_amdgcn_wave_barrier();
-        scan_steps(pm, L, q, n_leaf, k, bound, count);
+        t1 = pf.now();
+        pf.add(P_ROUNDS, t1 - t0); pf.add(P_N_ROUNDS, 1);
+        if (n_leaf > 0) c = scan_steps(pm, qx, qy, qz, n_leaf, k, c, pf);
+        pf.add(P_LEAVES, pf.now() - t1); pf.add(P_N_LEAVES, n_leaf);
         if (!fits) {
             // frontier full: walk this round's children serially instead, lane by lane
             unsigned long long todo = m_far | m_near;
@@ -351,16 +497,19 @@ __device__ void knn_collect(const PhotonMapView& pm, WaveLds& L, float qx, float
                 todo &= todo - 1;
                 int a_lo = __shfl(nlo, src), a_hi = __shfl(nhi, src), b_lo = __shfl(flo, src), b_hi = __shfl(fhi, src);
                 float b_dd = __shfl(dd, src);
-                if ((m_near >> src) & 1ull) walk_serial(pm, L, q, a_lo, a_hi, k, bound, count);
-                if (((m_far >> src) & 1ull) && !(b_dd > bound)) walk_serial(pm, L, q, b_lo, b_hi, k, bound, count);
+                if ((m_near >> src) & 1ull) c = walk_serial(pm, qx, qy, qz, a_lo, a_hi, k, c, pf);
+                if (((m_far >> src) & 1ull) && !(b_dd > c.bound)) c = walk_serial(pm, qx, qy, qz, b_lo, b_hi, k, c, pf);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (count > k) {
+    if (c.count > k) {
         __builtin_amdgcn_wave_barrier();
-        select_k(L, count, k);
+        t0 = pf.now();
+        c = select_k(c.count, k);
+        pf.add(P_SELECT, pf.now() - t0); pf.add(P_N_SELECT, 1);
     }
+    return c.count;
 }
 
 struct GatherParams {
@@ -382,9 +531,10 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 // Radiance estimate over the gathered set (main.cpp:262-295).  rgb is the clipped estimate.
-__device__ void estimate(const PhotonMapView& pm, const WaveLds& L, int count, const double* nrm, const double* col, double norm, double* rgb,
+__device__ void estimate(const PhotonMapView& pm, int count, const double* nrm, const double* col, double norm, double* rgb,
                          float* max_d2)
 {
+    const WaveLds& L = g_L;
     const int lane = lane_id();
     rgb[0] = rgb[1] = rgb[2] = 0.0;
     *max_d2 = -1.f;
@@ -393,19 +543,42 @@ __device__ void estimate(const PhotonMapView& pm, const WaveLds& L, int count, c
     for (int j = lane; j < count; j += WAVE) m = fmaxf(m, L.key[j]);
     const float maxDistSqr = wave_max(m);          // distance of the farthest returned photon (main.cpp:266-267)
     *max_d2 = maxDistSqr;
-    const double denom = 1 - pow(2.71828, -1.953);
+    // 2.71828^x evaluated as exp(x * ln 2.71828)
+    const double ln_base = 0.999999327347282;
+    const double denom = 1 - exp(-1.953 * ln_base);
+    // the two loop-invariant divisors of main.cpp:279 as reciprocals (the weight is rounded to float anyway)
+    const double inv_denom = 1.0 / denom, inv_2max = 1.0 / (2 * (double)maxDistSqr);
     double s0 = 0, s1 = 0, s2 = 0;
-    for (int j = lane; j < count; j += WAVE) {
-        float distanceSqr = L.key[j];
-        const float* a = pm.aux + 6 * (size_t)L.idx[j];
-        // gaussian filter, main.cpp:279 (float result of a double expression)
-        float weight = (float)(0.918 * (1 - (1 - pow(2.71828, -1.953 * (distanceSqr) / (2 * maxDistSqr))) / denom));
-        float cosine = (float)(nrm[0] * (-(double)a[3]) + nrm[1] * (-(double)a[4]) + nrm[2] * (-(double)a[5]));   // main.cpp:281-283
-        if (cosine < 0) cosine = -cosine;
-        double sc = (double)(cosine * weight);
-        s0 += (col[0] * (double)a[0]) * sc;        // main.cpp:286
-        s1 += (col[1] * (double)a[1]) * sc;
-        s2 += (col[2] * (double)a[2]) * sc;
+    constexpr int UNR = 4;       // photons per lane whose records are fetched together
+    for (int base = 0; base < count; base += UNR * WAVE) {
+        float dsq[UNR], a[UNR][6];
+        bool valid[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            int j = base + u * WAVE + lane;
+            valid[u] = j < count;
+            dsq[u] = 0.f;
+            if (valid[u]) {
+                dsq[u] = L.key[j];
+                const float* src = pm.aux + 6 * (size_t)L.idx[j];
+#pragma unroll
+                for (int c = 0; c < 6; c++) a[u][c] = src[c];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            if (valid[u]) {
+                float distanceSqr = dsq[u];
+                // gaussian filter, main.cpp:279 (float result of a double expression)
+                float weight = (float)(0.918 * (1 - (1 - exp(((-1.953 * (distanceSqr)) * inv_2max) * ln_base)) * inv_denom));
+                float cosine = (float)(nrm[0] * (-(double)a[u][3]) + nrm[1] * (-(double)a[u][4]) + nrm[2] * (-(double)a[u][5]));   // main.cpp:281-283
+                if (cosine < 0) cosine = -cosine;
+                double sc = (double)(cosine * weight);
+                s0 += (col[0] * (double)a[u][0]) * sc;        // main.cpp:286
+                s1 += (col[1] * (double)a[u][1]) * sc;
+                s2 += (col[2] * (double)a[u][2]) * sc;
+            }
+        }
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     double scale = 1.0 / (norm * maxDistSqr);      // main.cpp:293
@@ -422,12 +595,12 @@ __device__ void estimate(const PhotonMapView& pm, const WaveLds& L, int count, c
 // Requests differ a lot in cost, so the (single-wave) blocks of the persistent grid draw them from
 // a shared counter -- several per draw while plenty are left, one near the end; a request takes
 // tens of microseconds, which keeps the draw rate far below what one counter word sustains.
-__global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const GatherRec* __restrict__ recs, const rtq::Counts* cnt,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_kernel(PhotonMapView pm, const GatherRec* __restrict__ recs, const rtq::Counts* cnt,
                                                       unsigned long long shard_cap, unsigned long long* next, GatherParams gp,
                                                       double* __restrict__ acc)
 {
-    __shared__ WaveLds L;
     const int lane = lane_id();
+    const Prof pf{nullptr};
     const rtq::Map map = rtq::map_units(cnt, shard_cap, 1);
     const uint32_t n = map.total;
     uint32_t q_end = 0;
@@ -445,12 +618,11 @@ __global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const Ga
             uint32_t first, n_shard;
             rtq::locate(map, q, 1, shard, first, n_shard);
             const GatherRec& r = recs[(unsigned long long)shard * shard_cap + first];
-            int count;
-            knn_collect(pm, L, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, count);
+            const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, pf);
             __builtin_amdgcn_wave_barrier();
             double rgb[3];
             float md2;
-            estimate(pm, L, count, r.normal, r.color, gp.norm, rgb, &md2);
+            estimate(pm, count, r.normal, r.color, gp.norm, rgb, &md2);
             if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * (lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2])));
             __builtin_amdgcn_wave_barrier();
         }
@@ -458,26 +630,31 @@ __global__ __launch_bounds__(WAVE) void gather_kernel(PhotonMapView pm, const Ga
 }
 
 // Batch form for the ABI test hooks: query q -> count, max d2, clipped estimate
-__global__ __launch_bounds__(WAVE) void knn_batch_kernel(PhotonMapView pm, long long n, const double* __restrict__ pos, const double* __restrict__ nrm,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void knn_batch_kernel(PhotonMapView pm, long long n, const double* __restrict__ pos, const double* __restrict__ nrm,
                                                          const double* __restrict__ col, GatherParams gp, int* __restrict__ counts,
                                                          double* __restrict__ r2_out, double* __restrict__ rgb_out, int* __restrict__ idx_out,
-                                                         unsigned long long* next)
+                                                         unsigned long long* next, unsigned long long* prof)
 {
-    __shared__ WaveLds L;
+    const WaveLds& L = g_L;
     const int lane = lane_id();
+    const Prof pf{prof};
+    pf.init();
+    __builtin_amdgcn_wave_barrier();
     while (true) {
         unsigned long long q = 0;
         if (lane == 0) q = atomicAdd(next, 1ull);
         q = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q);
         if (q >= (unsigned long long)n) break;
-        int count;
-        knn_collect(pm, L, (float)pos[3 * q], (float)pos[3 * q + 1], (float)pos[3 * q + 2], gp.k, gp.r2, count);
+        const int count = knn_collect(pm, (float)pos[3 * q], (float)pos[3 * q + 1], (float)pos[3 * q + 2], gp.k, gp.r2, pf);
         __builtin_amdgcn_wave_barrier();
+        pf.add(P_QUERIES, 1);
         double rgb[3] = {0, 0, 0};
         float md2 = -1.f;
         if (nrm && col) {
             double nn[3] = {nrm[3 * q], nrm[3 * q + 1], nrm[3 * q + 2]}, cc[3] = {col[3 * q], col[3 * q + 1], col[3 * q + 2]};
-            estimate(pm, L, count, nn, cc, gp.norm, rgb, &md2);
+            unsigned long long t = pf.now();
+            estimate(pm, count, nn, cc, gp.norm, rgb, &md2);
+            pf.add(P_ESTIMATE, pf.now() - t);
         } else if (count > 0) {
             float m = 0.f;
             for (int j = lane; j < count; j += WAVE) m = fmaxf(m, L.key[j]);
@@ -493,6 +670,8 @@ __global__ __launch_bounds__(WAVE) void knn_batch_kernel(PhotonMapView pm, long 
         }
         __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_wave_barrier();
+    pf.flush();
 }
 
 }  // namespace rtg
