@@ -8,6 +8,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import torch  # noqa: E402  (first: torch carries its own HIP runtime and must be the one that initialises)
+torch.cuda.init()
 import raytracer_amd as rt  # noqa: E402
 
 DATA = os.path.join(ROOT, "tests", "golden", "data")
@@ -57,6 +59,35 @@ def main():
             rays = st.primary_rays + st.secondary_rays
             print(f"C4 water 1920x1080 k={k}: {rays} rays, {st.gather_queries} gathers, device {st.kernel_ms:.2f} ms "
                   f"(trace+shade {st.trace_kernel_ms:.2f} ms) -> {st.gather_queries / max(st.kernel_ms - st.trace_kernel_ms, 1e-9) / 1e3:.2f} Mqueries/s, host wall {dt*1e3:.0f} ms")
+    if "c5" in which:
+        n_inst = int(os.environ.get("C5_INST", "10000"))
+        side = int(np.ceil(np.sqrt(n_inst)))
+        s = rt.Scene()
+        t0 = time.perf_counter()
+        k = 0
+        for i in range(side):
+            for j in range(side):
+                if k < n_inst:
+                    s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0.0, i * 1.5, j * 1.5))
+                    k += 1
+        t1 = time.perf_counter()
+        s.build_bvh()
+        t2 = time.perf_counter()
+        ctx.upload(s)
+        t3 = time.perf_counter()
+        print(f"C5 host: {s.size()} triangles loaded in {t1 - t0:.1f} s, BVH (depth {s.bvh_depth()}) built in {t2 - t1:.1f} s, upload {t3 - t2:.1f} s", flush=True)
+        c = side * 1.5 / 2
+        cam = rt.look_at((side * 1.5 * 0.6, c, c), (0.0, c, c))
+        w, h = 7680, 4320
+        buf = torch.empty((2, h, w), dtype=torch.int32, device="cuda")
+        for prec, name in ((rt.RT_F64, "f64"), (rt.RT_F32, "f32")):
+            for shadow in (0, 1):
+                p = rt.default_params(width=w, height=h, precision=prec, shadow_rays=shadow, light_pos=(side * 1.5, c, c))
+                for _ in range(2):
+                    st = ctx.trace_primary_dev(cam, p, (0, h), buf[0].data_ptr(), None, buf[1].data_ptr())
+                rays = st.primary_rays + st.shadow_rays
+                hits = int((buf[0] >= 0).sum().item())
+                print(f"C5 {name} {w}x{h} shadow={shadow}: {rays} rays ({hits} primary hits), kernel {st.trace_kernel_ms:.2f} ms -> {rays / st.trace_kernel_ms / 1e3:.0f} Mrays/s", flush=True)
 
 
 if __name__ == "__main__":
