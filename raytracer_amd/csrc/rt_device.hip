@@ -147,6 +147,14 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
 // per-wave stacks; the block size is chosen to keep the most waves resident per CU.
 struct TraceGeom { int threads, blocks; size_t lds; bool nodes_in_lds; };
 
+// RT_GATHER_FRONT_CAP=<n> (32 <= n <= FRONT) shrinks the gather's frontier so that tests reach its serial walk
+int gather_front_cap()
+{
+    const char* e = getenv("RT_GATHER_FRONT_CAP");
+    int v = e ? atoi(e) : rtg::FRONT;
+    return std::max(32, std::min(v, rtg::FRONT));
+}
+
 template <class R>
 int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g)
 {
@@ -644,6 +652,7 @@ int knn_launch(rt_context* ctx, int which, int k, double max_dist, int photon_nu
     if (col) HIP_TRY(hipMemcpyAsync(d_col, col, b3, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     rtg::GatherParams gp;
+    gp.front_cap = gather_front_cap();
     gp.k = k;
     gp.r2 = (float)(max_dist * max_dist);
     gp.norm = (double)(photon_num / 16) * 3.1415926;            // PHOTONMUM/16*PI, integer division first (main.cpp:293)
@@ -745,6 +754,7 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     if (p->use_photon_map && ctx->pm[0].n > 0) {
         rtg::GatherParams gp;
+        gp.front_cap = gather_front_cap();
         gp.k = p->photon_use;
         gp.r2 = (float)(p->photon_dist * p->photon_dist);
         gp.norm = (double)(p->photon_num / 16) * 3.1415926;

@@ -394,7 +394,7 @@ __device__ __attribute__((noinline)) Cand walk_serial(PhotonMapView pm, float qx
 
 // k nearest photons within sqrt(r2) of one query held identically by all lanes.  Returns the
 // number of photons found; g_L.key / g_L.idx[0..count) is the set.
-__device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, Prof pf)
+__device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, int front_cap, Prof pf)
 {
     WaveLds& L = g_L;
     const int lane = lane_id();
@@ -476,7 +476,7 @@ __device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, fl
             L.c_lo[r] = rlo;
             L.c_n[r] = rhi - rlo;
         }
-        const bool fits = nf + n_far + n_near <= FRONT;
+        const bool fits = nf + n_far + n_near <= front_cap;
         if (fits) {
             // far sides below near sides: the near sides are taken first
             if (push_far) { int p = nf + (int)prefix_rank(m_far); L.f_lo[p] = flo; L.f_hi[p] = fhi; L.f_d2[p] = dd; }
@@ -516,6 +516,7 @@ struct GatherParams {
     int k;
     float r2;
     double norm;      // PHOTONMUM / 16 * PI  (integer division first, main.cpp:293)
+    int front_cap;    // frontier entries in use (<= FRONT; smaller values only to test the serial walk)
 };
 
 // reduce a double over the wave (all lanes get lane 0's total after the final shuffle)
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             uint32_t first, n_shard;
             rtq::locate(map, q, 1, shard, first, n_shard);
             const GatherRec& r = recs[(unsigned long long)shard * shard_cap + first];
-            const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, pf);
+            const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, gp.front_cap, pf);
             __builtin_amdgcn_wave_barrier();
             double rgb[3];
             float md2;
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         if (lane == 0) q = atomicAdd(next, 1ull);
         q = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q);
         if (q >= (unsigned long long)n) break;
-        const int count = knn_collect(pm, (float)pos[3 * q], (float)pos[3 * q + 1], (float)pos[3 * q + 2], gp.k, gp.r2, pf);
+        const int count = knn_collect(pm, (float)pos[3 * q], (float)pos[3 * q + 1], (float)pos[3 * q + 2], gp.k, gp.r2, gp.front_cap, pf);
         __builtin_amdgcn_wave_barrier();
         pf.add(P_QUERIES, 1);
         double rgb[3] = {0, 0, 0};

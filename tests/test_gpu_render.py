@@ -188,3 +188,40 @@ def test_render_f32_instantiation(gpu_ctx):
     a, _, _ = gpu_ctx.render(cam, rt.default_params(width=128, height=96))
     b, _, _ = gpu_ctx.render(cam, rt.default_params(width=128, height=96, precision=rt.RT_F32))
     assert_image_close(b, a, frac=0.99, rmse_max=3.0, what="f32 vs f64")
+
+
+def _d2_f32(pos32, c32):
+    d = pos32 - c32
+    return (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+
+
+@pytest.mark.parametrize("front_cap", [None, "32"])
+def test_knn_stress_paths(gpu_ctx, front_cap, monkeypatch):
+    """Large radius over a volume-filling cloud (many subtrees inside the bound: the frontier
+    overflows into the serial walk) plus thousands of coincident photons (crowded histogram bins:
+    the select falls back to its radix passes, ties at the k-th distance).  Count and k-th distance
+    must equal a full sort in the same float32 arithmetic.  The second run shrinks the frontier to 32
+    entries (a launch-time setting of the library) so that the serial walk is certainly reached."""
+    if front_cap:
+        monkeypatch.setenv("RT_GATHER_FRONT_CAP", front_cap)
+    rng = np.random.default_rng(11)
+    n = 200_000
+    ph = np.zeros((n, 9))
+    ph[:, :3] = rng.uniform(-1, 1, (n, 3))
+    ph[:6000, :3] = np.array([0.25, -0.5, 0.125])            # coincident cluster
+    ph[6000:9000, :3] = np.array([0.25, -0.5, 0.125]) + rng.normal(0, 1e-4, (3000, 3))
+    ph[:, 3:6] = 1.0
+    ph[:, 6:9] = np.array([0.0, -1.0, 0.0])
+    gpu_ctx.photons_upload(ph)
+    pos32 = ph[:, :3].astype(np.float32)
+    centers = np.concatenate([rng.uniform(-1, 1, (24, 3)), np.array([[0.25, -0.5, 0.125], [0.26, -0.5, 0.125], [0.0, 0.0, 0.0]])])
+    centers = centers.astype(np.float32).astype(np.float64)
+    for k, radius in ((1000, 5.0), (1000, 0.28), (64, 5.0), (1792, 0.5)):
+        cnt, r2 = gpu_ctx.knn_radius(k, centers, max_dist=radius)
+        lim = np.float32(radius * radius)
+        for q in range(len(centers)):
+            dd = np.sort(_d2_f32(pos32, centers[q].astype(np.float32)))
+            within = dd[dd < lim][:k]
+            assert cnt[q] == len(within), (k, radius, q, cnt[q], len(within))
+            if len(within):
+                assert np.float32(r2[q]) == within[-1], (k, radius, q, r2[q], within[-1])

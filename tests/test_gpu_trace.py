@@ -1,12 +1,13 @@
 """GPU parity of the closest-hit path (through the C ABI) against the CPU oracle and the golden
 vectors of the compiled reference.  f64 instantiation: ids and t bit-exact."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
 import raytracer_amd as rt
-from conftest import CAM, build_scene, golden, golden_hashes
+from conftest import CAM, DATA, build_scene, golden, golden_hashes
 from oracle.bindings import Oracle, id_map_hash
 
 pytestmark = pytest.mark.gpu
@@ -143,3 +144,34 @@ def test_bvh_equals_brute_force_on_gpu(gpu_ctx, scenes):
     bids, bt = orc.brute_force(org, d)
     assert eq(t, bt)
     assert (ids == bids).mean() > 0.999
+
+
+def test_instanced_grid_deep_tree(gpu_ctx):
+    """49 teapots on a grid (48 608 triangles, a tree about 17 levels deep, node array too large
+    for LDS staging): primary and random rays bit-exact against the oracle, both entry points."""
+    def build(s):
+        for i in range(7):
+            for j in range(7):
+                s.load_obj(os.path.join(DATA, "teapot_normal.obj"), off=(0.0, i * 1.5, j * 1.5))
+        s.build_bvh()
+        return s
+    scene, orc = build(rt.Scene()), build(Oracle())
+    assert scene.bvh_depth() >= 14
+    gpu_ctx.upload(scene)
+    cam_v = np.array([9.0, 4.5, 4.5, 0.0, 4.5, 4.5])
+    w, h = 320, 200
+    ids, t, _, _ = gpu_ctx.trace_primary(rt.look_at(cam_v[:3], cam_v[3:]), rt.default_params(width=w, height=h))
+    org, d = orc.primary_rays(w, h, cam_v)
+    oid, ot = orc.shoot(org, d)
+    assert (oid >= 0).mean() > 0.2
+    assert np.array_equal(ids, oid)
+    assert np.array_equal(np.where(ids >= 0, t, 1e9), ot)
+    rng = np.random.default_rng(5)
+    n = 50_000
+    o = rng.uniform(-1, 10, (n, 3))
+    dd = rng.normal(size=(n, 3))
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    gid, gt = gpu_ctx.trace_closest(o, dd)
+    rid, rdist = orc.shoot(o, dd)
+    assert np.array_equal(gid, rid)
+    assert np.array_equal(gt, rdist)
