@@ -93,7 +93,7 @@ struct rt_context {
     DevBuf ph_pos[2], ph_aux[2], ph_axis[2], ph_order[2];
     rtg::PhotonMapView pm[2] = {};
     // render queues
-    DevBuf hits_a, hits_b, gq, acc;
+    DevBuf hits_a, hits_b, rays, gq, acc;
     // staging for the host-buffer convenience entry points
     DevBuf st_org, st_dir, st_dist, st_ids, st_aux;
 };
@@ -262,7 +262,7 @@ void rt_context_destroy(rt_context* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
-                      &ctx->hits_b, &ctx->gq, &ctx->acc, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
+                      &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
                       &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1]})
         b->release();
     for (auto& ev : ctx->ev)
@@ -714,6 +714,40 @@ int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const
 
 namespace {
 
+// the three traversal kernels of the render path for one (R, TRI_ONLY, NLDS) choice
+template <class R, bool TRI_ONLY, bool NLDS>
+int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceGeom& g, int levels, unsigned long long shard_cap,
+                         rtr::RenderCounters* ctr)
+{
+    const int rows = a.row_end - a.row_begin;
+    const int cap = stack_cap(ctx);
+    rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
+    const int64_t tiles = (int64_t)((a.width + 7) / 8) * ((rows + 7) / 8);
+    const int wpb = g.threads / 64;
+    hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, NLDS>), dim3((unsigned)((tiles + wpb - 1) / wpb)), dim3(g.threads), g.lds, ctx->stream,
+                       view<R>(ctx), a, (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes);
+    HIP_TRY(hipGetLastError());
+    // persistent grids for the queue consumers (their work counts live in device memory)
+    const int trace_blocks_cu = std::max(1, std::min<int>((int)(160 * 1024 / std::max<size_t>(g.lds, 1)), 12 / wpb));
+    const int trace_blocks = ctx->num_cus * trace_blocks_cu;
+    const int shade_blocks = ctx->num_cus * 4;
+    rtr::HitRec* qin = (rtr::HitRec*)ctx->hits_a.p;
+    rtr::HitRec* qout = (rtr::HitRec*)ctx->hits_b.p;
+    for (int level = 1; level <= levels; level++) {
+        const int last = level == levels ? 1 : 0;
+        hipLaunchKernelGGL(rtr::shade_kernel, dim3(shade_blocks), dim3(rtk::BLOCK), 0, ctx->stream, sd, a, level, last, qin, (rtr::RayRec*)ctx->rays.p,
+                           (rtg::GatherRec*)ctx->gq.p, shard_cap, ctr);
+        HIP_TRY(hipGetLastError());
+        if (!last) {
+            hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, NLDS>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
+                               (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes);
+            HIP_TRY(hipGetLastError());
+        }
+        std::swap(qin, qout);
+    }
+    return RT_OK;
+}
+
 template <class R>
 int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, double* d_acc, rtr::RenderCounters* host_ctr)
 {
@@ -728,29 +762,20 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     int rc;
     if ((rc = ctx->hits_a.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
     if ((rc = ctx->hits_b.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
+    if ((rc = ctx->rays.reserve(cap_total * sizeof(rtr::RayRec)))) return rc;
     if ((rc = ctx->gq.reserve(cap_total * sizeof(rtg::GatherRec)))) return rc;
-    int cap = stack_cap(ctx);
-    size_t lds = rtk::stack_lds_bytes(cap, sizeof(R));
-    if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
+    TraceGeom g;
+    if ((rc = trace_geometry<R>(ctx, ctx->n_nodes, &g))) return rc;
     rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
     HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)a.width * rows * 3 * sizeof(double), ctx->stream));
-    int blocks = grid_blocks(ctx, lds);
-    rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
-    const int64_t tiles = (int64_t)((a.width + 7) / 8) * ((rows + 7) / 8);
-    const int waves_per_block = rtk::BLOCK / 64;
-    hipLaunchKernelGGL((rtr::render_primary_kernel<R>), dim3((unsigned)((tiles + waves_per_block - 1) / waves_per_block)), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), a,
-                       (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap);
-    HIP_TRY(hipGetLastError());
-    rtr::HitRec* qin = (rtr::HitRec*)ctx->hits_a.p;
-    rtr::HitRec* qout = (rtr::HitRec*)ctx->hits_b.p;
-    for (int level = 1; level <= levels; level++) {
-        hipLaunchKernelGGL((rtr::shade_level_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), sd, a, level,
-                           level == levels ? 1 : 0, qin, qout, shard_cap, (rtg::GatherRec*)ctx->gq.p, ctr, cap);
-        HIP_TRY(hipGetLastError());
-        std::swap(qin, qout);
-    }
+    const bool tri_only = view<R>(ctx).tri_only;
+    if (tri_only && g.nodes_in_lds) rc = launch_render_levels<R, true, true>(ctx, a, g, levels, shard_cap, ctr);
+    else if (tri_only) rc = launch_render_levels<R, true, false>(ctx, a, g, levels, shard_cap, ctr);
+    else if (g.nodes_in_lds) rc = launch_render_levels<R, false, true>(ctx, a, g, levels, shard_cap, ctr);
+    else rc = launch_render_levels<R, false, false>(ctx, a, g, levels, shard_cap, ctr);
+    if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     if (p->use_photon_map && ctx->pm[0].n > 0) {
         rtg::GatherParams gp;

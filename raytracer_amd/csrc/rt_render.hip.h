@@ -1,10 +1,13 @@
 // Pixel path as a wavefront of queues in HBM (replaces the recursion of getColorAt, main.cpp:158-392):
 //
 //   render_primary_kernel   camera rays (main.cpp:753-790) + BVH::Shoot -> hit queue level 1
-//   shade_level_kernel x D  per queued hit: colour, normal, material branch (main.cpp:164-258);
-//                           mirror / glass hits trace their reflection / refraction ray at once and
-//                           append the next level's hits (ballot-compacted); diffuse hits append a
-//                           gather request
+//   per level d = 1..D:
+//   shade_kernel            per queued hit: colour, normal, material branch (main.cpp:164-258);
+//                           mirror / glass hits append their reflection / refraction rays to the
+//                           ray queue, diffuse hits append a gather request (all ballot-compacted)
+//   trace_queue_kernel      per queued ray: BVH::Shoot, append the next level's hit.  Tracing from
+//                           its own compacted queue keeps all 64 lanes busy in the expensive part
+//                           (in a hit queue only the mirror / glass entries have rays to trace)
 //   gather_kernel           photon k-NN + radiance estimate per request (rt_gather.hip.h)
 //   resolve_kernel          average, clip, quantise (main.cpp:853-859, IO.cpp:55-65)
 //
@@ -34,8 +37,19 @@ struct HitRec {
     int32_t obj;        // object to shade
 };
 
+// a secondary ray waiting to be traced
+struct RayRec {
+    double org[3];      // hit_pos of the surface it leaves (main.cpp:162)
+    double dir[3];
+    double weight;      // throughput of the path once this ray is followed
+    uint32_t pixel;     // bit 31: refraction ray (child position uses accuracy + t, main.cpp:246)
+    int32_t obj;        // object the ray leaves (HEAD recursion shades it again, main.cpp:198,249)
+};
+constexpr uint32_t RAY_REFRACT = 0x80000000u;
+
 struct RenderCounters {
     rtq::Counts hits[MAX_LEVELS + 2];   // hits[d] = fill of the bounce queue of level d (1-based)
+    rtq::Counts rays[MAX_LEVELS + 2];   // rays[d] = fill of the ray queue produced by shading level d
     rtq::Counts gather;                 // fill of the gather queue
     unsigned long long overflow_stack, overflow_queue;
     unsigned long long secondary_rays;
@@ -58,12 +72,14 @@ struct RenderArgs {
     int head_quirk, use_photon_map;
 };
 
-template <class R>
-__global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits, unsigned long long shard_cap,
-                                                               RenderCounters* ctr, int cap)
+template <class R, bool TRI_ONLY, bool NLDS>
+__global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits,
+                                                                       unsigned long long shard_cap, RenderCounters* ctr, int cap, int n_nodes)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    LaneStack st = rtk::make_stack<R>(lds, cap);
+    const size_t node_bytes = NLDS ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
+    if (NLDS) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0;
     const int rows = a.row_end - a.row_begin;
@@ -87,7 +103,7 @@ __global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R>
                 R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
                 R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
                 R dist = R(1e9);
-                int id = rtk::trace_ray<R>(sv, o, d, dist, st, &ovf_stack);
+                int id = rtk::trace_ray<R, false, TRI_ONLY, NLDS>(sv, o, d, dist, st, &ovf_stack);
                 if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
                     double t = (double)dist;
                     rec.pos[0] = a.cam_pos[0] + dd.x * t; rec.pos[1] = a.cam_pos[1] + dd.y * t; rec.pos[2] = a.cam_pos[2] + dd.z * t;   // :821
@@ -105,16 +121,13 @@ __global__ __launch_bounds__(BLOCK) void render_primary_kernel(rtf::SceneView<R>
     if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
 }
 
-// One recursion level of getColorAt for every queued hit.
-template <class R>
-__global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv, ShadeData sd, RenderArgs a, int level, int last_level,
-                                                            const HitRec* __restrict__ in, HitRec* __restrict__ out, unsigned long long shard_cap,
-                                                            rtg::GatherRec* __restrict__ gq, RenderCounters* ctr, int cap)
+// One recursion level of getColorAt for every queued hit, up to the point where it would call Shoot.
+__global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a, int level, int last_level, const HitRec* __restrict__ in,
+                                                      RayRec* __restrict__ rays, rtg::GatherRec* __restrict__ gq, unsigned long long shard_cap,
+                                                      RenderCounters* ctr)
 {
-    extern __shared__ __align__(16) unsigned char lds[];
-    LaneStack st = rtk::make_stack<R>(lds, cap);
-    uint32_t ovf_stack = 0;
-    unsigned long long ovf_queue = 0, n_secondary = 0;
+    const int lane = threadIdx.x & 63;
+    unsigned long long ovf_queue = 0;
     // the queue length lives in device memory, so the grid is persistent; chunks of 64 hits are dealt
     // round-robin to the waves (no shared work counter)
     const rtq::Map map = rtq::map_units(&ctr->hits[level], shard_cap, WAVE);
@@ -122,9 +135,9 @@ __global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv
         unsigned shard;
         uint32_t first, n_shard;
         rtq::locate(map, chunk, WAVE, shard, first, n_shard);
-        const uint32_t i = first + st.lane;
+        const uint32_t i = first + lane;
         bool active = i < n_shard;
-        HitRec next[2];
+        RayRec next[2];
         bool want[2] = {false, false};
         rtg::GatherRec g;
         bool want_g = false;
@@ -140,24 +153,12 @@ __global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv
             if (special > 0) {
                 if (!last_level) {   // children of the last level return black (main.cpp:161): not traced
                     rtm::D3 Rd = rtm::reflect_dir(hit_normal, hit_dir);            // main.cpp:170
-                    R o[3] = {(R)hit_pos.x, (R)hit_pos.y, (R)hit_pos.z};
-                    {
-                        R d[3] = {(R)Rd.x, (R)Rd.y, (R)Rd.z};
-                        R dist = R(1e9);
-                        int io = rtk::trace_ray<R>(sv, o, d, dist, st, &ovf_stack);   // main.cpp:190-191
-                        n_secondary++;
-                        double t = (double)dist;
-                        bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:193
-                        if (go) {
-                            rtm::D3 np = rtm::vadd(hit_pos, rtm::vmul(Rd, t));     // main.cpp:195
-                            next[0].pos[0] = np.x; next[0].pos[1] = np.y; next[0].pos[2] = np.z;
-                            next[0].dir[0] = Rd.x; next[0].dir[1] = Rd.y; next[0].dir[2] = Rd.z;
-                            next[0].weight = special > 1 ? rec.weight * (2 - special) : rec.weight;   // main.cpp:200-203
-                            next[0].pixel = rec.pixel;
-                            next[0].obj = a.head_quirk ? rec.obj : io;             // main.cpp:198
-                            want[0] = true;
-                        }
-                    }
+                    next[0].org[0] = hit_pos.x; next[0].org[1] = hit_pos.y; next[0].org[2] = hit_pos.z;
+                    next[0].dir[0] = Rd.x; next[0].dir[1] = Rd.y; next[0].dir[2] = Rd.z;                  // main.cpp:190-191
+                    next[0].weight = special > 1 ? rec.weight * (2 - special) : rec.weight;              // main.cpp:200-203
+                    next[0].pixel = rec.pixel;
+                    next[0].obj = rec.obj;
+                    want[0] = true;
                     if (special > 1) {                                             // main.cpp:210-258
                         double refractance = special - 1;
                         double n1n2 = 1.0 / obj.ior;
@@ -172,21 +173,12 @@ __global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv
                         if (underSQRT > 0) {
                             double coeffN = nNL - sqrt(underSQRT);
                             rtm::D3 T = rtm::vadd(rtm::vmul(hit_normal, coeffN), rtm::vneg(rtm::vmul(rtm::vneg(hit_dir), n1n2)));   // main.cpp:233
-                            R d[3] = {(R)T.x, (R)T.y, (R)T.z};
-                            R dist = R(1e9);
-                            int io = rtk::trace_ray<R>(sv, o, d, dist, st, &ovf_stack);   // main.cpp:242-243
-                            n_secondary++;
-                            double t = (double)dist;
-                            bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:245
-                            if (go) {
-                                rtm::D3 np = rtm::vadd(hit_pos, rtm::vmul(T, a.accuracy + t));   // main.cpp:246
-                                next[1].pos[0] = np.x; next[1].pos[1] = np.y; next[1].pos[2] = np.z;
-                                next[1].dir[0] = T.x; next[1].dir[1] = T.y; next[1].dir[2] = T.z;
-                                next[1].weight = rec.weight * refractance;          // main.cpp:251
-                                next[1].pixel = rec.pixel;
-                                next[1].obj = a.head_quirk ? rec.obj : io;          // main.cpp:249
-                                want[1] = true;
-                            }
+                            next[1].org[0] = hit_pos.x; next[1].org[1] = hit_pos.y; next[1].org[2] = hit_pos.z;
+                            next[1].dir[0] = T.x; next[1].dir[1] = T.y; next[1].dir[2] = T.z;            // main.cpp:242-243
+                            next[1].weight = rec.weight * refractance;                                   // main.cpp:251
+                            next[1].pixel = rec.pixel | RAY_REFRACT;
+                            next[1].obj = rec.obj;
+                            want[1] = true;
                         }
                     }
                 }
@@ -200,9 +192,55 @@ __global__ __launch_bounds__(BLOCK) void shade_level_kernel(rtf::SceneView<R> sv
                 want_g = true;
             }
         }
-        rtq::push(out, &ctr->hits[level + 1], shard_cap, want[0], next[0], &ovf_queue);
-        rtq::push(out, &ctr->hits[level + 1], shard_cap, want[1], next[1], &ovf_queue);
+        rtq::push(rays, &ctr->rays[level], shard_cap, want[0], next[0], &ovf_queue);
+        rtq::push(rays, &ctr->rays[level], shard_cap, want[1], next[1], &ovf_queue);
         rtq::push(gq, &ctr->gather, shard_cap, want_g, g, &ovf_queue);
+    }
+    if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
+}
+
+// Shoot for every queued ray of a level; hits become the next level's queue (main.cpp:190-199, 242-250).
+template <class R, bool TRI_ONLY, bool NLDS>
+__global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneView<R> sv, RenderArgs a, int level, const RayRec* __restrict__ rays,
+                                                                    HitRec* __restrict__ out, unsigned long long shard_cap, RenderCounters* ctr,
+                                                                    int cap, int n_nodes)
+{
+    extern __shared__ __align__(16) unsigned char lds[];
+    const size_t node_bytes = NLDS ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
+    if (NLDS) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
+    uint32_t ovf_stack = 0;
+    unsigned long long ovf_queue = 0, n_secondary = 0;
+    const rtq::Map map = rtq::map_units(&ctr->rays[level], shard_cap, WAVE);
+    for (uint32_t chunk = rtq::wave_index(); chunk < map.total; chunk += rtq::n_waves()) {
+        unsigned shard;
+        uint32_t first, n_shard;
+        rtq::locate(map, chunk, WAVE, shard, first, n_shard);
+        const uint32_t i = first + st.lane;
+        HitRec next;
+        bool want = false;
+        if (i < n_shard) {
+            const RayRec ray = rays[(unsigned long long)shard * shard_cap + i];
+            R o[3] = {(R)ray.org[0], (R)ray.org[1], (R)ray.org[2]};
+            R d[3] = {(R)ray.dir[0], (R)ray.dir[1], (R)ray.dir[2]};
+            R dist = R(1e9);
+            int io = rtk::trace_ray<R, false, TRI_ONLY, NLDS>(sv, o, d, dist, st, &ovf_stack);
+            n_secondary++;
+            double t = (double)dist;
+            bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:193,245
+            if (go) {
+                rtm::D3 org = {ray.org[0], ray.org[1], ray.org[2]}, dir = {ray.dir[0], ray.dir[1], ray.dir[2]};
+                const bool refract = (ray.pixel & RAY_REFRACT) != 0;
+                rtm::D3 np = rtm::vadd(org, rtm::vmul(dir, refract ? a.accuracy + t : t));   // main.cpp:195, 246
+                next.pos[0] = np.x; next.pos[1] = np.y; next.pos[2] = np.z;
+                next.dir[0] = dir.x; next.dir[1] = dir.y; next.dir[2] = dir.z;
+                next.weight = ray.weight;
+                next.pixel = ray.pixel & ~RAY_REFRACT;
+                next.obj = a.head_quirk ? ray.obj : io;                          // main.cpp:198, 249
+                want = true;
+            }
+        }
+        rtq::push(out, &ctr->hits[level + 1], shard_cap, want, next, &ovf_queue);
     }
     if (ovf_stack) atomicMax(&ctr->overflow_stack, 1ull);
     if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
