@@ -84,6 +84,40 @@ __device__ __forceinline__ void locate(const Map& m, uint32_t u, uint32_t unit, 
     first = (u - (incl_s - units_s)) * unit;
 }
 
+// Dynamic assignment of a queue's work units to the waves of a persistent grid, for consumers whose
+// units differ a lot in cost.  One draw counter per shard (a single counter word would be the
+// bottleneck): a wave draws from its home shard until that is exhausted, then reads all draw
+// counters at once and moves to the next shard that still has units.
+struct Drawer {
+    unsigned home;
+};
+__device__ __forceinline__ Drawer drawer_init() { return Drawer{wave_index() & (SHARDS - 1)}; }
+
+// Must be called by all lanes of the wave.  Returns false when no unit is left anywhere.
+__device__ __forceinline__ bool draw(const Map& m, Counts* next, uint32_t unit, Drawer& d, uint32_t& u)
+{
+    const unsigned lane = lane_id();
+    const uint32_t my_units = (m.n + unit - 1) / unit;   // lane s: units of shard s
+    while (true) {
+        const uint32_t incl_s = __shfl(m.incl, (int)d.home);
+        const uint32_t units_s = __shfl(my_units, (int)d.home);
+        if (units_s > 0) {
+            unsigned long long k = 0;
+            if (lane == 0) k = atomicAdd(&next->n[d.home][0], 1ull);
+            k = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(k >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)k);
+            if (k < units_s) {
+                u = incl_s - units_s + (uint32_t)k;
+                return true;
+            }
+        }
+        unsigned long long taken = lane < (unsigned)SHARDS ? __hip_atomic_load(&next->n[lane][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ~0ull;
+        const unsigned long long avail = __ballot(lane < (unsigned)SHARDS && taken < my_units);
+        if (avail == 0) return false;
+        const unsigned long long after = d.home + 1 < 64 ? avail & ~((1ull << (d.home + 1)) - 1ull) : 0ull;
+        d.home = (unsigned)__builtin_ctzll(after ? after : avail);
+    }
+}
+
 inline unsigned long long host_total(const Counts& c, unsigned long long shard_cap)
 {
     unsigned long long t = 0;

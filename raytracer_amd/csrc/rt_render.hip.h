@@ -50,6 +50,7 @@ constexpr uint32_t RAY_REFRACT = 0x80000000u;
 struct RenderCounters {
     rtq::Counts hits[MAX_LEVELS + 2];   // hits[d] = fill of the bounce queue of level d (1-based)
     rtq::Counts rays[MAX_LEVELS + 2];   // rays[d] = fill of the ray queue produced by shading level d
+    rtq::Counts ray_draws[MAX_LEVELS + 2];   // chunks of rays[d] handed out to the tracing waves
     rtq::Counts gather;                 // fill of the gather queue
     unsigned long long overflow_stack, overflow_queue;
     unsigned long long secondary_rays;
@@ -211,8 +212,11 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
     LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0, n_secondary = 0;
+    // secondary rays differ a lot in cost: chunks of 64 are drawn dynamically (per-shard draw counters)
     const rtq::Map map = rtq::map_units(&ctr->rays[level], shard_cap, WAVE);
-    for (uint32_t chunk = rtq::wave_index(); chunk < map.total; chunk += rtq::n_waves()) {
+    rtq::Drawer drawer = rtq::drawer_init();
+    uint32_t chunk;
+    while (rtq::draw(map, &ctr->ray_draws[level], WAVE, drawer, chunk)) {
         unsigned shard;
         uint32_t first, n_shard;
         rtq::locate(map, chunk, WAVE, shard, first, n_shard);
