@@ -162,11 +162,13 @@ def main():
         ids32 = buf[0].cpu().numpy().ravel()
         parity["f32_id_mismatch_fraction"] = float((ids32 != ids).mean())
 
-    traffic = None
+    traffic = valu_busy = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(args.precision)
+            prof = json.load(open(tpath))
+            traffic = prof.get(args.precision)
+            valu_busy = prof.get(args.precision + "_valu_busy")
         except Exception:
             traffic = None
 
@@ -199,6 +201,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic,
+            "valu_busy": valu_busy,
             "kernel": "trace_primary_kernel<%s>" % ("double" if prec == rt.RT_F64 else "float"),
             "kernel_ms_avg": round(avg_kernel_ms, 4),
             "kernel_ms_single_launch": round(single_kernel_ms, 4),

@@ -260,6 +260,33 @@ def main():
             np.savez_compressed(os.path.join(GOLD, f"render_{tag}_64.npz"), rgb=rgb.reshape(h, w, 3), bmp=np.fromfile(pr, np.uint8),
                                 photons=ref.photons_get()[:, :9], rgbs=np.array(rgbs), ior=ior)
 
+    # ---------------------------------------------------------------- G8: subsurface material (main.cpp:297-388)
+    # the reference's getColorAt on a teapot with special < 0: surface estimate + volume gather + the 2-pass march
+    # (its RNG seeded; the restatement consumes the same sequence when it shades the same hits in the same order)
+    ref = Reference(); orc = Oracle()
+    sss = (0.9, 0.7, 0.6, -1.0)
+    build_scene(ref, "teapot_normal.obj", sss, 1.3, (0, -0.7, 0)); build_scene(orc, "teapot_normal.obj", sss, 1.3, (0, -0.7, 0))
+    ref.seed(12345); orc.seed(12345)
+    nr = ref.emit_photons(20000); no = orc.emit_photons(20000)
+    check(f"photon count sss ({nr})", nr, no)
+    check("volume photon records sss", ref.photons_get(1)[:, :9], orc.photons_get(1)[:, :9])
+    surf, vol = ref.photons_get(0)[:, :9].copy(), ref.photons_get(1)[:, :9].copy()
+    print(f"   {len(surf)} surface photons, {len(vol)} volume photons")
+    ref.build_kdtree(); orc.build_kdtree()
+    w = h = 64
+    org, d = ref.primary_rays(w, h, CAM)
+    ids, t = ref.shoot(org, d)
+    hit = (ids >= 0) & (t > 1e-6)
+    pos = org[hit] + d[hit] * t[hit][:, None]
+    ref.seed(777); orc.seed(777)
+    rcol = ref.get_color_at(pos, d[hit], ids[hit], 1); ocol = orc.get_color_at(pos, d[hit], ids[hit], 1)
+    check("getColorAt subsurface teapot (same RNG sequence)", rcol, ocol)
+    rgb = np.zeros((w * h, 3)); rgb[hit] = rcol
+    n_sss = int((ids[hit] < 992).sum())
+    print(f"   {n_sss} subsurface pixels")
+    np.savez_compressed(os.path.join(GOLD, "render_sss_64.npz"), rgb=rgb.reshape(h, w, 3), photons=surf, volume_photons=vol,
+                        rgbs=np.array(sss), ior=1.3)
+
     print()
     if failures:
         print("FAILED:", failures)

@@ -44,6 +44,15 @@ for k in {k for (k, c) in means}:
         fs, ws = means.get((k, "FETCH_SIZE")), means.get((k, "WRITE_SIZE"))
         if fs is not None and ws is not None:
             traffic[prec] = int((2 * fs + ws) * 1024)
+        # VALU busy = cycles the SIMDs spend issuing VALU instructions / cycles available:
+        # SQ_ACTIVE_INST_VALU counts in units of 4 cycles, summed over the chip's 1024 SIMDs;
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        av, gui = means.get((k, "SQ_ACTIVE_INST_VALU")), means.get((k, "GRBM_GUI_ACTIVE"))
+        if av is not None and gui:
+            traffic[prec + "_valu_busy"] = round(av * 4 / 1024 / (gui / 8), 4)
+        wc, wa, wi = means.get((k, "SQ_WAVE_CYCLES")), means.get((k, "SQ_WAIT_ANY")), means.get((k, "SQ_WAIT_INST_ANY"))
+        if wc and gui:
+            traffic[prec + "_waves_per_simd"] = round(wc * 4 / 1024 / (gui / 8), 3)
 if traffic:
     traffic["_source"] = f"profiles/{tag}_pmc.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch of trace_primary_kernel"
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)

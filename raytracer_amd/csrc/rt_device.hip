@@ -777,13 +777,15 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     else rc = launch_render_levels<R, false, false>(ctx, a, g, levels, shard_cap, ctr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
-    if (p->use_photon_map && ctx->pm[0].n > 0) {
+    if (p->use_photon_map && (ctx->pm[0].n > 0 || ctx->pm[1].n > 0)) {
         rtg::GatherParams gp;
         gp.front_cap = gather_front_cap();
         gp.k = p->photon_use;
         gp.r2 = (float)(p->photon_dist * p->photon_dist);
         gp.norm = (double)(p->photon_num / 16) * 3.1415926;
-        hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], (const rtg::GatherRec*)ctx->gq.p,
+        gp.photon_num = (double)p->photon_num;
+        gp.seed = 12345u;
+        hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], (const rtg::GatherRec*)ctx->gq.p,
                            &ctr->gather, shard_cap, &ctr->next_gather, gp, d_acc);
         HIP_TRY(hipGetLastError());
     }

@@ -50,8 +50,10 @@ struct GatherRec {
     double color[3];
     double weight;               // path throughput the estimate is scaled by
     uint32_t pixel;
-    uint32_t pad;
+    uint32_t flags;              // GATHER_SSS: subsurface material (main.cpp:297); GATHER_MARCH: refraction possible (main.cpp:337)
+    double march[3];             // refracted direction the volume march follows (main.cpp:339)
 };
+constexpr uint32_t GATHER_SSS = 1u, GATHER_MARCH = 2u;
 
 // Optional cycle accounting (development aid): slots of the array a kernel is given.
 enum ProfSlot { P_DESCENT, P_SCAN0, P_SELECT, P_N_SELECT, P_ROUNDS, P_N_ROUNDS, P_LEAVES, P_N_LEAVES, P_ESTIMATE, P_QUERIES, P_SLOTS };
@@ -517,6 +519,8 @@ struct GatherParams {
     float r2;
     double norm;      // PHOTONMUM / 16 * PI  (integer division first, main.cpp:293)
     int front_cap;    // frontier entries in use (<= FRONT; smaller values only to test the serial walk)
+    double photon_num;   // PHOTONMUM as a double: the volume normaliser divides in floating point (main.cpp:332)
+    uint32_t seed;       // of the march's step lengths (main.cpp:374)
 };
 
 // reduce a double over the wave (all lanes get lane 0's total after the final shuffle)
@@ -531,8 +535,8 @@ __device__ __forceinline__ float wave_max(float v)
     return __shfl(v, 0);
 }
 
-// Radiance estimate over the gathered set (main.cpp:262-295).  rgb is the clipped estimate.
-__device__ void estimate(const PhotonMapView& pm, int count, const double* nrm, const double* col, double norm, double* rgb,
+// Radiance estimate over the gathered set (main.cpp:262-295), before the final clip.
+__device__ void estimate_raw(const PhotonMapView& pm, int count, const double* nrm, const double* col, double norm, double* rgb,
                          float* max_d2)
 {
     const WaveLds& L = g_L;
@@ -583,20 +587,74 @@ __device__ void estimate(const PhotonMapView& pm, int count, const double* nrm, 
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     double scale = 1.0 / (norm * maxDistSqr);      // main.cpp:293
-    double v[3] = {s0 * scale, s1 * scale, s2 * scale};
-    for (int c = 0; c < 3; c++) {                  // Color::clip, Color.h:39-57
+    rgb[0] = s0 * scale; rgb[1] = s1 * scale; rgb[2] = s2 * scale;
+}
+
+__device__ __forceinline__ void clip3(double* v)   // Color::clip, Color.h:39-57
+{
+    for (int c = 0; c < 3; c++) {
         double x = v[c];
         if (x > 1) x = 1;
         if (x < 0) x = 0;
-        rgb[c] = x;
+        v[c] = x;
     }
+}
+
+__device__ __forceinline__ void estimate(const PhotonMapView& pm, int count, const double* nrm, const double* col, double norm, double* rgb,
+                                         float* max_d2)
+{
+    estimate_raw(pm, count, nrm, col, norm, rgb, max_d2);
+    clip3(rgb);
+}
+
+// One step of the subsurface term (main.cpp:310-334, 346-373) over the volume photons gathered
+// around `centre`: sum of hit_color * power * 0.2, normalised by e^pass * PHOTONMUM / 8 * PI * m * sqrt(m)
+// where m is the squared distance from HIT_POS to the photon farthest from the centre (the
+// reference measures it against hit_pos in the march too, main.cpp:353).  Adds to sss[3].
+__device__ void volume_step(const PhotonMapView& vm, int count, const float* hit_pos, const double* col, double e_pass, double photon_num,
+                            double* sss)
+{
+    const WaveLds& L = g_L;
+    const int lane = lane_id();
+    if (count == 0) return;
+    double p0 = 0, p1 = 0, p2 = 0;
+    float far_key = -1.f;
+    uint32_t far_idx = 0;
+    for (int j = lane; j < count; j += WAVE) {
+        float key = L.key[j];
+        uint32_t id = L.idx[j];
+        const float* a = vm.aux + 6 * (size_t)id;
+        p0 += (col[0] * (double)a[0]) * 0.2;      // main.cpp:329, 368
+        p1 += (col[1] * (double)a[1]) * 0.2;
+        p2 += (col[2] * (double)a[2]) * 0.2;
+        if (key > far_key) { far_key = key; far_idx = id; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        float ok = __shfl_xor(far_key, off);
+        uint32_t oi = __shfl_xor(far_idx, off);
+        if (ok > far_key || (ok == far_key && oi < far_idx)) { far_key = ok; far_idx = oi; }
+    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+    const float* fp = vm.pos + 3 * (size_t)far_idx;
+    float dx = hit_pos[0] - fp[0], dy = hit_pos[1] - fp[1], dz = hit_pos[2] - fp[2];
+    float m = dx * dx + dy * dy + dz * dz;        // maxDistSqr, main.cpp:317, 353
+    double scale = 1.0 / (e_pass * photon_num / 8 * 3.1415926 * m * sqrtf(m));   // main.cpp:332, 371
+    sss[0] += p0 * scale; sss[1] += p1 * scale; sss[2] += p2 * scale;
+}
+
+// uniform in (0, 1) from a counter: the march's step length needs one per pass and sample
+__device__ __forceinline__ double unit_random(uint32_t a, uint32_t b, uint32_t seed)
+{
+    uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ seed * 0xC2B2AE3Du;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return ((double)x + 0.5) * (1.0 / 4294967296.0);
 }
 
 // Gather queue consumer: acc[3*pixel..] += weight * clip(estimate).  One request per wave at a time.
 // Requests differ a lot in cost, so the (single-wave) blocks of the persistent grid draw them from
 // a shared counter -- several per draw while plenty are left, one near the end; a request takes
 // tens of microseconds, which keeps the draw rate far below what one counter word sustains.
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_kernel(PhotonMapView pm, const GatherRec* __restrict__ recs, const rtq::Counts* cnt,
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_kernel(PhotonMapView pm, PhotonMapView vm, const GatherRec* __restrict__ recs, const rtq::Counts* cnt,
                                                       unsigned long long shard_cap, unsigned long long* next, GatherParams gp,
                                                       double* __restrict__ acc)
 {
@@ -623,7 +681,30 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             __builtin_amdgcn_wave_barrier();
             double rgb[3];
             float md2;
-            estimate(pm, count, r.normal, r.color, gp.norm, rgb, &md2);
+            estimate_raw(pm, count, r.normal, r.color, gp.norm, rgb, &md2);
+            if ((r.flags & GATHER_SSS) && vm.n > 0) {                       // main.cpp:297-388
+                const float hp[3] = {(float)r.pos[0], (float)r.pos[1], (float)r.pos[2]};
+                double sss[3] = {0, 0, 0};
+                __builtin_amdgcn_wave_barrier();
+                int vc = knn_collect(vm, hp[0], hp[1], hp[2], gp.k, gp.r2, gp.front_cap, pf);
+                __builtin_amdgcn_wave_barrier();
+                volume_step(vm, vc, hp, r.color, 1.0, gp.photon_num, sss);
+                if (r.flags & GATHER_MARCH) {
+                    double px = r.pos[0] + r.march[0] * 0.02, py = r.pos[1] + r.march[1] * 0.02, pz = r.pos[2] + r.march[2] * 0.02;   // main.cpp:341
+                    double e_pass = 2.71828;
+                    for (int pass = 1; pass < 3; pass++) {
+                        __builtin_amdgcn_wave_barrier();
+                        vc = knn_collect(vm, (float)px, (float)py, (float)pz, gp.k, gp.r2, gp.front_cap, pf);
+                        __builtin_amdgcn_wave_barrier();
+                        volume_step(vm, vc, hp, r.color, e_pass, gp.photon_num, sss);
+                        double d = -log(unit_random(r.pixel, (uint32_t)(q * 2 + pass), gp.seed)) / 200;   // main.cpp:374
+                        px += r.march[0] * d; py += r.march[1] * d; pz += r.march[2] * d;
+                        e_pass *= 2.71828;
+                    }
+                }
+                rgb[0] += sss[0]; rgb[1] += sss[1]; rgb[2] += sss[2];      // main.cpp:389
+            }
+            clip3(rgb);                                                    // main.cpp:391
             if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * (lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2])));
             __builtin_amdgcn_wave_barrier();
         }

@@ -189,7 +189,27 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
                 g.color[0] = col[0]; g.color[1] = col[1]; g.color[2] = col[2];
                 g.weight = rec.weight;
                 g.pixel = rec.pixel;
-                g.pad = 0;
+                g.flags = 0;
+                g.march[0] = g.march[1] = g.march[2] = 0;
+                if (special < 0) {                                                 // main.cpp:297-308, 337-339
+                    g.flags = rtg::GATHER_SSS;
+                    double n1n2 = 1.0 / obj.ior;
+                    double dot1 = rtm::vdot(hit_normal, rtm::vneg(hit_dir));
+                    rtm::D3 n = hit_normal;      // the estimate above keeps the un-flipped normal
+                    if (dot1 < 0) {
+                        n = rtm::vneg(n);
+                        dot1 = rtm::vdot(n, rtm::vneg(hit_dir));
+                        n1n2 = 1.0 / n1n2;
+                    }
+                    double nNL = n1n2 * dot1;
+                    double underSQRT = 1 - n1n2 * n1n2 * (1 - dot1 * dot1);
+                    if (underSQRT > 0) {
+                        double coeffN = nNL - sqrt(underSQRT);
+                        rtm::D3 T = rtm::vadd(rtm::vmul(n, coeffN), rtm::vneg(rtm::vmul(rtm::vneg(hit_dir), n1n2)));
+                        g.march[0] = T.x; g.march[1] = T.y; g.march[2] = T.z;
+                        g.flags |= rtg::GATHER_MARCH;
+                    }
+                }
                 want_g = true;
             }
         }

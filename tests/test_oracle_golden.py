@@ -191,3 +191,23 @@ def test_render_head_semantics(tag, tmp_path):
     p = str(tmp_path / "o.bmp")
     orc.save_bmp(p, 64, 64, rgb)
     assert eq(np.fromfile(p, np.uint8), g["bmp"])
+
+
+def test_subsurface_shading():
+    """getColorAt on a teapot with special < 0 (main.cpp:297-388): surface estimate, volume gather and
+    the two-pass march with the eye-path RNG seeded like the compiled reference was."""
+    g = golden("render_sss_64.npz")
+    orc = build_scene(Oracle(), "teapot_normal.obj", tuple(g["rgbs"]), float(g["ior"]), (0, -0.7, 0))
+    orc.seed(12345)
+    orc.emit_photons(20000)
+    assert eq(orc.photons_get(0)[:, :9], g["photons"])
+    assert eq(orc.photons_get(1)[:, :9], g["volume_photons"])
+    orc.build_kdtree()
+    org, d = orc.primary_rays(64, 64, CAM)
+    ids, t = orc.shoot(org, d)
+    hit = (ids >= 0) & (t > 1e-6)
+    pos = org[hit] + d[hit] * t[hit][:, None]
+    orc.seed(777)
+    rgb = np.zeros((64 * 64, 3))
+    rgb[hit] = orc.get_color_at(pos, d[hit], ids[hit], 1)
+    assert eq(rgb.reshape(64, 64, 3), g["rgb"])
