@@ -147,6 +147,15 @@ int rt_scene_get_triangle(const rt_scene* s, int obj, double points[9], double n
  * stored photons stay in the scene: which = 0 surface map (main.cpp:44), 1 volume map (main.cpp:45);
  * rt_scene_photons_get copies n x 9 doubles (position, power rgb, direction; Photon.h:7-28). */
 int rt_scene_emit_photons(rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy);
+/* The same emission on the GPU (one photon per lane through the closest-hit kernel's traversal):
+ * every photon owns a counter-based random stream keyed by (seed, photon number), so the photon
+ * list has the reference's distribution but not its serial std::mt19937 order -- the reference's
+ * own multi-threaded emission (main.cpp:689-720, one generator shared by all threads without
+ * synchronisation) is not reproducible either.  `s` must be the scene last uploaded to `ctx`.
+ * Photons are appended to the scene's lists in (photon number, bounce) order, independent of the
+ * launch.  stats (optional): secondary_rays = Shoot calls, kernel_ms. */
+int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce,
+                              double accuracy, rt_stats* stats);
 int64_t rt_scene_photon_count(const rt_scene* s, int which);
 int rt_scene_photons_get(const rt_scene* s, int which, double* photons);
 void rt_scene_photons_clear(rt_scene* s);

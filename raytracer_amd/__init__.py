@@ -109,6 +109,13 @@ class Scene:
         _chk(lib.rt_scene_emit_photons(self.h, n_emit, _dp(_f64(light_pos)), seed, bounce, accuracy), "rt_scene_emit_photons")
         return self.photon_count(0)
 
+    def emit_photons_gpu(self, ctx, n_emit, light_pos=(0.1, 0.2, 0.0), seed=12345, bounce=5, accuracy=1e-6):
+        """The same emission on the GPU (per-photon random streams); the scene must be the one uploaded to ctx."""
+        st = Stats()
+        _chk(lib.rt_scene_emit_photons_gpu(ctx.h, self.h, n_emit, _dp(_f64(light_pos)), seed, bounce, accuracy, ctypes.byref(st)),
+             "rt_scene_emit_photons_gpu")
+        return st
+
     def photon_count(self, which=0):
         return lib.rt_scene_photon_count(self.h, which)
 

@@ -73,6 +73,7 @@ PROTOTYPES = {
     "rt_scene_bvh_depth": (c_i, [vp]),
     "rt_scene_get_triangle": (c_i, [vp, c_i, P(c_d), P(c_d), P(c_d), P(c_i)]),
     "rt_scene_emit_photons": (c_i, [vp, c_i64, P(c_d), ctypes.c_uint32, c_i, c_d]),
+    "rt_scene_emit_photons_gpu": (c_i, [vp, vp, c_i64, P(c_d), ctypes.c_uint32, c_i, c_d, P(Stats)]),
     "rt_scene_photon_count": (c_i64, [vp, c_i]),
     "rt_scene_photons_get": (c_i, [vp, c_i, P(c_d)]),
     "rt_scene_photons_clear": (None, [vp]),

@@ -63,16 +63,7 @@ int host_shoot(const Scene& s, const double* o, const double* d, double& dist)
 // ---------------------------------------------------------------- emission
 namespace {
 
-// FresnelEquation, main.cpp:111-123 (single-precision arithmetic as there)
-double fresnel(float cosThetaI, float n1, float n2, int type)
-{
-    float sin2ThetaT = (n1 / n2) * (n1 / n2) * (1 - cosThetaI * cosThetaI);
-    float cosThetaT = sqrtf(1 - sin2ThetaT);
-    float Rs = (n1 * cosThetaI - n2 * cosThetaT) / (n1 * cosThetaI + n2 * cosThetaT);
-    float Rp = (n2 * cosThetaI - n1 * cosThetaT) / (n2 * cosThetaI + n1 * cosThetaT);
-    if (type == 0) return (Rs * Rs + Rp * Rp) / 2;
-    return 1 - (Rs * Rs + Rp * Rp) / 2;
-}
+using rtm::fresnel;
 
 const double PI_REF = 3.1415926;   // main.cpp:24
 

@@ -16,6 +16,7 @@
 #include "rt_gather.hip.h"
 #include "rt_kernels.hip.h"
 #include "rt_math.h"
+#include "rt_emit.hip.h"
 #include "rt_render.hip.h"
 
 namespace {
@@ -427,6 +428,86 @@ int rt_scene_emit_photons(rt_scene* s, int64_t n_emit, const double light_pos[3]
     ep.bounce = bounce;
     ep.accuracy = accuracy;
     rth::emit_photons(s->s, n_emit, light_pos, seed, ep, s->photons[0], s->photons[1]);
+    return RT_OK;
+}
+int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy,
+                              rt_stats* stats)
+{
+    if (!ctx || !s || !light_pos || n_emit < 0 || bounce < 0 || bounce > 7) return fail(RT_ERR_INVALID, "bad argument");
+    if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
+    if ((int64_t)s->s.objects.size() != ctx->n_objects) return fail(RT_ERR_STATE, "the scene is not the one uploaded to this context");
+    int rc;
+    if ((rc = use_device(ctx))) return rc;
+    const int cap = stack_cap(ctx);
+    const size_t lds = rtk::stack_lds_bytes(cap, sizeof(double));
+    if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
+    const int64_t batch = 1 << 20;
+    // a photon stores at most once per bounce level, and scatters at most 4 volume photons (a subsurface hit ends the walk)
+    const unsigned long long cap_s = ((unsigned long long)batch * (bounce + 1) + rtq::SHARDS - 1) / rtq::SHARDS + 16384;
+    const unsigned long long cap_v = ((unsigned long long)batch * 4 + rtq::SHARDS - 1) / rtq::SHARDS + 16384;
+    if ((rc = ctx->hits_a.reserve(cap_s * rtq::SHARDS * sizeof(rte::PhotonOut)))) return rc;
+    if ((rc = ctx->hits_b.reserve(cap_v * rtq::SHARDS * sizeof(rte::PhotonOut)))) return rc;
+    if ((rc = ctx->counters.reserve(sizeof(rte::EmitCounters)))) return rc;
+    std::vector<rte::PhotonOut> host[2];
+    rte::ShadeTables sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
+    rte::EmitCounters* ctr = (rte::EmitCounters*)ctx->counters.p;
+    uint64_t rays = 0;
+    float ms_total = 0;
+    for (int64_t first = 0; first < n_emit; first += batch) {
+        rte::EmitArgs a;
+        for (int i = 0; i < 3; i++) a.light[i] = light_pos[i];
+        a.n_emit = std::min(batch, n_emit - first);
+        a.first = first;
+        a.seed = seed;
+        a.bounce = bounce;
+        a.accuracy = accuracy;
+        HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rte::EmitCounters), ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        hipLaunchKernelGGL((rte::emit_kernel<double>), dim3((unsigned)((a.n_emit + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), lds, ctx->stream,
+                           ctx->v64, sd, a, (rte::PhotonOut*)ctx->hits_a.p, cap_s, (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        rte::EmitCounters hc;
+        HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (hc.overflow_stack) return fail(RT_ERR_LIMIT, "traversal stack overflow");
+        if (hc.overflow_queue) return fail(RT_ERR_LIMIT, "photon queue overflow");
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        ms_total += ms;
+        rays += hc.rays;
+        for (int which = 0; which < 2; which++) {
+            const rtq::Counts& c = which ? hc.volume : hc.surface;
+            const unsigned long long shard_cap = which ? cap_v : cap_s;
+            const rte::PhotonOut* dev = (const rte::PhotonOut*)(which ? ctx->hits_b.p : ctx->hits_a.p);
+            for (int sh = 0; sh < rtq::SHARDS; sh++) {
+                size_t n = (size_t)std::min<unsigned long long>(c.n[sh][0], shard_cap);
+                if (!n) continue;
+                size_t at = host[which].size();
+                host[which].resize(at + n);
+                HIP_TRY(hipMemcpyAsync(host[which].data() + at, dev + (size_t)sh * shard_cap, n * sizeof(rte::PhotonOut), hipMemcpyDeviceToHost, ctx->stream));
+            }
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    for (int which = 0; which < 2; which++) {
+        std::vector<uint32_t> order(host[which].size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
+        const rte::PhotonOut* h = host[which].data();
+        std::sort(order.begin(), order.end(), [h](uint32_t x, uint32_t y) { return h[x].key < h[y].key; });
+        auto& out = s->photons[which];
+        out.reserve(out.size() + order.size());
+        for (uint32_t i : order) {
+            rth::PhotonRec r;
+            memcpy(&r, &h[i], sizeof r);
+            out.push_back(r);
+        }
+    }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->secondary_rays = rays;
+        stats->kernel_ms = stats->trace_kernel_ms = ms_total;
+    }
     return RT_OK;
 }
 int64_t rt_scene_photon_count(const rt_scene* s, int which) { return (s && (which == 0 || which == 1)) ? (int64_t)s->photons[which].size() : -1; }

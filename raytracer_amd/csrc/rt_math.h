@@ -257,6 +257,17 @@ RT_HD D3 obj_normal(const rtf::ObjShade& p, D3 pt)
     return ld3(p.A);
 }
 
+// FresnelEquation, main.cpp:111-123 (single-precision arithmetic as there)
+RT_HD double fresnel(float cosThetaI, float n1, float n2, int type)
+{
+    float sin2ThetaT = (n1 / n2) * (n1 / n2) * (1 - cosThetaI * cosThetaI);
+    float cosThetaT = sqrtf(1 - sin2ThetaT);
+    float Rs = (n1 * cosThetaI - n2 * cosThetaT) / (n1 * cosThetaI + n2 * cosThetaT);
+    float Rp = (n2 * cosThetaI - n1 * cosThetaT) / (n2 * cosThetaI + n1 * cosThetaT);
+    if (type == 0) return (Rs * Rs + Rp * Rp) / 2;
+    return 1 - (Rs * Rs + Rp * Rp) / 2;
+}
+
 // Triangle::getTangentAt (Triangle.h:242-256), Sphere::getTangentAt (Sphere.h:40-42)
 RT_HD D3 obj_tangent(const rtf::ObjShade& p, D3 pt)
 {

@@ -21,13 +21,18 @@ class Renderer {
 public:
     explicit Renderer(BVH* b) : bvh(b) {}
 
-    // main.cpp:697-718 on one thread with a seeded generator; appends `new Photon`s (caller owns them)
+    // main.cpp:697-718; appends `new Photon`s (caller owns them).  on_device = false: one host thread
+    // with a seeded std::mt19937, the reference's serial photon list; true: the same walk on the GPU
+    // with one random stream per photon (same distribution, much faster).
     void emitPhotons(long long n_emit, Vect light_position, unsigned seed, std::vector<Photon*>& photons, std::vector<Photon*>& volumePhotons,
-                     int bounce = 5, double accuracy = 0.000001)
+                     int bounce = 5, double accuracy = 0.000001, bool on_device = false)
     {
         rt_scene* s = bvh->host_scene();
         rt_scene_photons_clear(s);
-        rt::check(rt_scene_emit_photons(s, n_emit, light_position.data(), seed, bounce, accuracy), "rt_scene_emit_photons");
+        if (on_device)
+            rt::check(rt_scene_emit_photons_gpu(rt::device(), s, n_emit, light_position.data(), seed, bounce, accuracy, nullptr), "rt_scene_emit_photons_gpu");
+        else
+            rt::check(rt_scene_emit_photons(s, n_emit, light_position.data(), seed, bounce, accuracy), "rt_scene_emit_photons");
         for (int which = 0; which < 2; which++) {
             long long n = rt_scene_photon_count(s, which);
             std::vector<double> flat((size_t)n * 9);

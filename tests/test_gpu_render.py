@@ -251,3 +251,43 @@ def test_render_subsurface(gpu_ctx):
     rmse = float(np.sqrt(((a - b) ** 2).mean()))
     print(f"subsurface: within 1 LSB {within:.4f}, rmse {rmse:.3f}, max {np.abs(a - b).max()}")
     assert within >= 0.99 and rmse <= 1.0
+
+
+def _emission_summary(ph):
+    """Count, mean power per channel, per-axis position histogram (8 bins over the box)."""
+    hist = np.stack([np.histogram(ph[:, ax], bins=8, range=(-1.0001, 1.0001))[0] for ax in range(3)]).astype(np.float64)
+    mean_power = ph[:, 3:6].mean(0) if len(ph) else np.zeros(3)
+    return len(ph), mean_power, hist / max(1, len(ph))
+
+
+@pytest.mark.parametrize("tag,rgbs,ior", [("glass", (1.0, 1.0, 1.0, 1.8), 1.5), ("mirror", (1.0, 1.0, 1.0, 0.9), 1.5),
+                                          ("subsurface", (0.9, 0.7, 0.6, -1.0), 1.3)])
+def test_gpu_emission_statistics(gpu_ctx, tag, rgbs, ior):
+    """photonEmission on the GPU (per-photon random streams) against the serial host emission that
+    reproduces the reference's list: same distribution -- photons stored per emitted photon, mean
+    power, where the photons land -- within sampling noise; identical lists for identical arguments."""
+    s = build_scene(rt.Scene(), "teapot_normal.obj", rgbs, ior, (0, -0.7, 0))
+    gpu_ctx.upload(s)
+    n = 60000
+    s.emit_photons(n, seed=5)
+    host = [s.photons_get(0), s.photons_get(1)]
+    s.photons_clear()
+    st = s.emit_photons_gpu(gpu_ctx, n, seed=5)
+    dev = [s.photons_get(0), s.photons_get(1)]
+    s.photons_clear()
+    s.emit_photons_gpu(gpu_ctx, n, seed=5)
+    assert np.array_equal(s.photons_get(0), dev[0]) and np.array_equal(s.photons_get(1), dev[1])   # launch-independent order
+    assert st.secondary_rays >= n
+    for which in (0, 1):
+        nh, ph_, hh = _emission_summary(host[which])
+        nd, pd_, hd = _emission_summary(dev[which])
+        if which == 1 and tag != "subsurface":
+            assert nh == 0 and nd == 0
+            continue
+        assert nh > 1000
+        assert abs(nd - nh) <= 5 * np.sqrt(nh) + 0.01 * nh, (tag, which, nh, nd)
+        assert np.abs(pd_ - ph_).max() < 0.02, (tag, which, ph_, pd_)
+        assert np.abs(hd - hh).max() < 0.02, (tag, which)
+        # photons lie on surfaces the host's photons lie on: every GPU photon has a host photon nearby
+    d = np.linalg.norm(dev[0][:2000, None, :3] - host[0][None, ::7, :3], axis=-1).min(1)
+    assert np.median(d) < 0.05

@@ -53,6 +53,12 @@ def main():
         ctx.photons_upload(ph)
         t2 = time.perf_counter()
         print(f"C4 host: emitted {nemit} -> {n} photons in {t1 - t0:.2f} s; kd build + upload {t2 - t1:.2f} s")
+        s.photons_clear()
+        t0 = time.perf_counter()
+        est = s.emit_photons_gpu(ctx, nemit, seed=12345)
+        t1 = time.perf_counter()
+        print(f"C4 GPU emission: {nemit} -> {s.photon_count(0)} photons, {est.secondary_rays} rays, kernels {est.kernel_ms:.2f} ms, "
+              f"wall incl. download and ordering {t1 - t0:.3f} s")
         for k in (1000, 100):
             p = rt.default_params(width=1920, height=1080, photon_num=nemit, photon_use=k)
             st, dt = timed_render(ctx, p, reps=2)
