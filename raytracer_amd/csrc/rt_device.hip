@@ -146,7 +146,7 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
 
 // Launch geometry of the persistent traversal kernels.  LDS per block = node image (if staged) +
 // per-wave stacks; the block size is chosen to keep the most waves resident per CU.
-struct TraceGeom { int threads, blocks; size_t lds; bool nodes_in_lds; };
+struct TraceGeom { int threads, blocks; size_t lds; int mode; };   // mode: rtk::TRAV_*
 
 // RT_GATHER_FRONT_CAP=<n> (32 <= n <= FRONT) shrinks the gather's frontier so that tests reach its serial walk
 int gather_front_cap()
@@ -159,21 +159,35 @@ int gather_front_cap()
 template <class R>
 int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g)
 {
-    // Blocks of 4 waves (one 8x8 tile each); smaller blocks only when a deep tree's stacks would
-    // not fit. The node array is copied into each block's LDS when that copy is cheap next to the
-    // block's traversal work and leaves room for 3 blocks per CU.
+    // Blocks of 4 waves (one 8x8 tile each) unless a deep tree's stacks then leave fewer waves resident
+    // than smaller blocks would (LDS is the limit: depth x 64 lanes x bytes per entry, per wave).
+    // Deep trees switch to 4-byte stack entries with a box re-test at pop (TRAV_RETEST) when that
+    // keeps more waves resident; small trees copy their node array into each block's LDS
+    // (TRAV_NODES) when the copy is cheap next to the block's work and leaves room for 3 blocks per CU.
     const int cap = stack_cap(ctx);
-    const size_t per_wave = rtk::stack_lds_bytes(cap, sizeof(R), 1);
     const size_t lds_max = 160 * 1024;
-    const size_t node_bytes = rtk::node_lds_bytes<R>((size_t)n_nodes);
-    for (int w : {4, 2, 1}) {
-        size_t lds = w * per_wave;
-        if (lds > lds_max) continue;
-        bool nlds = w == 4 && n_nodes > 0 && node_bytes <= 24 * 1024 && 3 * (lds + node_bytes) <= lds_max && !getenv("RT_NO_NODE_LDS");
-        *g = TraceGeom{w * 64, 0, lds + (nlds ? node_bytes : 0), nlds};
-        return RT_OK;
+    const int vgpr_waves = 12;   // waves per CU the register budget of the traversal kernels admits
+    int best_w = 0, best_resident = 0, best_mode = rtk::TRAV_PLAIN;
+    const char* force = getenv("RT_TRAV_MODE");   // tuning aid: "plain" / "retest"
+    for (int mode : {rtk::TRAV_PLAIN, rtk::TRAV_RETEST}) {
+        if (force && ((force[0] == 'p') != (mode == rtk::TRAV_PLAIN))) continue;
+        const size_t per_wave = rtk::stack_lds_bytes(cap, mode == rtk::TRAV_RETEST ? 0 : sizeof(R), 1);
+        for (int w : {4, 2, 1}) {
+            size_t lds = w * per_wave;
+            if (lds > lds_max) continue;
+            int resident = std::min<int>((int)(lds_max / lds) * w, vgpr_waves);
+            if (resident > best_resident) { best_resident = resident; best_w = w; best_mode = mode; }
+        }
     }
-    return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack per wave (> 160 KiB per block)", ctx->depth, per_wave);
+    if (!best_w) return fail(RT_ERR_LIMIT, "BVH depth %d: the traversal stack of one wave does not fit 160 KiB of LDS", ctx->depth);
+    size_t lds = best_w * rtk::stack_lds_bytes(cap, best_mode == rtk::TRAV_RETEST ? 0 : sizeof(R), 1);
+    const size_t node_bytes = rtk::node_lds_bytes<R>((size_t)n_nodes);
+    if (best_mode == rtk::TRAV_PLAIN && best_w == 4 && n_nodes > 0 && node_bytes <= 24 * 1024 && 3 * (lds + node_bytes) <= lds_max && !getenv("RT_NO_NODE_LDS")) {
+        best_mode = rtk::TRAV_NODES;
+        lds += node_bytes;
+    }
+    *g = TraceGeom{best_w * 64, 0, lds, best_mode};
+    return RT_OK;
 }
 
 template <class R, bool COUNT, bool TRI_ONLY>
@@ -187,12 +201,13 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
     int64_t tiles = (int64_t)((a.width + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
     int wpb = g.threads / 64;
     int blocks = (int)std::max<int64_t>(1, (tiles + wpb - 1) / wpb);
-    if (g.nodes_in_lds)
-        hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, true>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
-                           d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes);
-    else
-        hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, false>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
-                           d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes);
+#define RT_LAUNCH_PRIMARY(MODE)                                                                                                              \
+    hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, \
+                       d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes)
+    if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_PRIMARY(rtk::TRAV_NODES);
+    else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_PRIMARY(rtk::TRAV_RETEST);
+    else RT_LAUNCH_PRIMARY(rtk::TRAV_PLAIN);
+#undef RT_LAUNCH_PRIMARY
     HIP_TRY(hipGetLastError());
     return RT_OK;
 }
@@ -795,8 +810,8 @@ int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const
 
 namespace {
 
-// the three traversal kernels of the render path for one (R, TRI_ONLY, NLDS) choice
-template <class R, bool TRI_ONLY, bool NLDS>
+// the three traversal kernels of the render path for one (R, TRI_ONLY, MODE) choice
+template <class R, bool TRI_ONLY, int MODE>
 int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceGeom& g, int levels, unsigned long long shard_cap,
                          rtr::RenderCounters* ctr)
 {
@@ -805,7 +820,7 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int64_t tiles = (int64_t)((a.width + 7) / 8) * ((rows + 7) / 8);
     const int wpb = g.threads / 64;
-    hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, NLDS>), dim3((unsigned)((tiles + wpb - 1) / wpb)), dim3(g.threads), g.lds, ctx->stream,
+    hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE>), dim3((unsigned)((tiles + wpb - 1) / wpb)), dim3(g.threads), g.lds, ctx->stream,
                        view<R>(ctx), a, (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes);
     HIP_TRY(hipGetLastError());
     // persistent grids for the queue consumers (their work counts live in device memory)
@@ -820,7 +835,7 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
                            (rtg::GatherRec*)ctx->gq.p, shard_cap, ctr);
         HIP_TRY(hipGetLastError());
         if (!last) {
-            hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, NLDS>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
+            hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
                                (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes);
             HIP_TRY(hipGetLastError());
         }
@@ -852,10 +867,15 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)a.width * rows * 3 * sizeof(double), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     const bool tri_only = view<R>(ctx).tri_only;
-    if (tri_only && g.nodes_in_lds) rc = launch_render_levels<R, true, true>(ctx, a, g, levels, shard_cap, ctr);
-    else if (tri_only) rc = launch_render_levels<R, true, false>(ctx, a, g, levels, shard_cap, ctr);
-    else if (g.nodes_in_lds) rc = launch_render_levels<R, false, true>(ctx, a, g, levels, shard_cap, ctr);
-    else rc = launch_render_levels<R, false, false>(ctx, a, g, levels, shard_cap, ctr);
+    if (tri_only) {
+        if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, true, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr);
+        else if (g.mode == rtk::TRAV_RETEST) rc = launch_render_levels<R, true, rtk::TRAV_RETEST>(ctx, a, g, levels, shard_cap, ctr);
+        else rc = launch_render_levels<R, true, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr);
+    } else {
+        if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, false, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr);
+        else if (g.mode == rtk::TRAV_RETEST) rc = launch_render_levels<R, false, rtk::TRAV_RETEST>(ctx, a, g, levels, shard_cap, ctr);
+        else rc = launch_render_levels<R, false, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr);
+    }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
     if (p->use_photon_map && (ctx->pm[0].n > 0 || ctx->pm[1].n > 0)) {

@@ -17,6 +17,15 @@ constexpr int BLOCK = 256;
 constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
 constexpr int MAX_BLOCK = 768;   // register budget of the traversal kernels: compiled for 3 waves per SIMD (<= 168 VGPRs)
 
+// How a traversal kernel keeps its nodes and its stack:
+//   TRAV_PLAIN    nodes read through L1; stack entries (child ref, entry distance)
+//   TRAV_NODES    small trees: node array copied into the block's LDS; same stack
+//   TRAV_RETEST   deep trees: stack entries are 4 bytes (parent node, which child) and the deferred
+//                 child's box is tested again when it is popped -- the reference's own entry
+//                 re-test (BVH.cpp:132) -- so a third of the LDS per wave buys three times the
+//                 resident waves where the stack depth limits occupancy
+constexpr int TRAV_PLAIN = 0, TRAV_NODES = 1, TRAV_RETEST = 2;
+
 struct LaneStack {
     uint32_t* ref;   // [depth][64] for this wave
     void* t0;        // [depth][64] of R
@@ -47,12 +56,12 @@ __device__ __forceinline__ void stage_nodes(uint4* dst, const rtf::Node<R>* node
     __syncthreads();
 }
 
-template <class R, bool NLDS>
+template <class R, int MODE>
 __device__ __forceinline__ rtf::Node<R> fetch_node(const rtf::Node<R>* __restrict__ nodes, const uint4* lds_nodes, uint32_t idx)
 {
     constexpr int CH = NodeLds<R>::CHUNKS, ST = NodeLds<R>::STRIDE;
     uint4 v[sizeof(rtf::Node<R>) / 16];
-    const uint4* src = NLDS ? lds_nodes + (size_t)idx * ST : reinterpret_cast<const uint4*>(nodes + idx);
+    const uint4* src = MODE == TRAV_NODES ? lds_nodes + (size_t)idx * ST : reinterpret_cast<const uint4*>(nodes + idx);
 #pragma unroll
     for (int i = 0; i < CH; i++) v[i] = src[i];
     rtf::Node<R> out;
@@ -125,7 +134,7 @@ __device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims
 //     what the pop compares (t0 travels on the stack);
 //   - rays with a non-finite reciprocal direction or origin (axis-parallel rays: 0 * inf = NaN in
 //     the slab test) take the literal path below, which re-runs the full slab test on entry.
-template <class R, bool COUNT = false, bool TRI_ONLY = false, bool NLDS = false>
+template <class R, bool COUNT = false, bool TRI_ONLY = false, int MODE = TRAV_PLAIN>
 __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R& dist, const LaneStack& st, uint32_t* overflow,
                          WorkCount* wc = nullptr)
 {
@@ -145,7 +154,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                 int sp = 0;
                 while (true) {
                     if (!(cur & rtf::LEAF_BIT)) {
-                        const rtf::Node<R> nd = fetch_node<R, NLDS>(sv.nodes, st.lds_nodes, cur);
+                        const rtf::Node<R> nd = fetch_node<R, MODE>(sv.nodes, st.lds_nodes, cur);
                         if (COUNT) wc->inner++;
                         R td0 = rtm::slab_finite<R>(nd.lo0, nd.hi0, o, inv, dist);
                         R td1 = rtm::slab_finite<R>(nd.lo1, nd.hi1, o, inv, dist);
@@ -154,8 +163,12 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                         if (h0 && h1) {
                             bool first0 = td0 < td1;
                             if (sp < st.cap) {
-                                s_ref[sp * WAVE + lane] = first0 ? c1 : c0;
-                                s_t0[sp * WAVE + lane] = first0 ? td1 : td0;
+                                if (MODE == TRAV_RETEST) {
+                                    s_ref[sp * WAVE + lane] = (cur << 1) | (first0 ? 1u : 0u);
+                                } else {
+                                    s_ref[sp * WAVE + lane] = first0 ? c1 : c0;
+                                    s_t0[sp * WAVE + lane] = first0 ? td1 : td0;
+                                }
                                 sp++;
                             } else {
                                 *overflow = 1;
@@ -171,8 +184,17 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                     bool found = false;
                     while (sp > 0) {
                         sp--;
-                        R t0 = s_t0[sp * WAVE + lane];
-                        if (!(t0 > dist)) { cur = s_ref[sp * WAVE + lane]; found = true; break; }
+                        if (MODE == TRAV_RETEST) {
+                            const uint32_t e = s_ref[sp * WAVE + lane];
+                            const rtf::Node<R>& pn = sv.nodes[e >> 1];
+                            const bool second = e & 1u;
+                            R lo[3], hi[3];
+                            for (int i = 0; i < 3; i++) { lo[i] = second ? pn.lo1[i] : pn.lo0[i]; hi[i] = second ? pn.hi1[i] : pn.hi0[i]; }
+                            if (!(rtm::slab_finite<R>(lo, hi, o, inv, dist) < R(0))) { cur = second ? pn.c1 : pn.c0; found = true; break; }   // BVH.cpp:132
+                        } else {
+                            R t0 = s_t0[sp * WAVE + lane];
+                            if (!(t0 > dist)) { cur = s_ref[sp * WAVE + lane]; found = true; break; }
+                        }
                     }
                     if (!found) break;
                 }
@@ -269,6 +291,7 @@ __device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, siz
     return st;
 }
 
+// real_size = 0 for TRAV_RETEST (no entry distances)
 inline size_t stack_lds_bytes(int cap, size_t real_size, int waves = WAVES_PER_BLOCK) { return (size_t)waves * cap * WAVE * (sizeof(uint32_t) + real_size); }
 
 // counters[0] = work counter, counters[1] = stack-overflow flag, counters[2] = shadow rays traced
@@ -307,14 +330,14 @@ struct PrimaryArgs {
 // Pixel loop front end: camera ray (always generated in double, then rounded to R) + BVH::Shoot
 // with distance 1e9 (main.cpp:812-813); optional shadow ray toward the light.
 // Work unit = 8x8 pixel tile per wave.
-template <class R, bool COUNT, bool TRI_ONLY, bool NLDS>
+template <class R, bool COUNT, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView<R> sv, PrimaryArgs a, int* __restrict__ ids,
                                                                   double* __restrict__ t_out, int* __restrict__ shadow_ids,
                                                                   TraceCounters* ctr, int cap, int n_nodes)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    const size_t node_bytes = NLDS ? node_lds_bytes<R>((size_t)n_nodes) : 0;
-    if (NLDS) stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    const size_t node_bytes = MODE == TRAV_NODES ? node_lds_bytes<R>((size_t)n_nodes) : 0;
+    if (MODE == TRAV_NODES) stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
     LaneStack st = make_stack<R>(lds, cap, node_bytes);
     uint32_t overflow = 0;
     unsigned long long n_shadow = 0;
@@ -336,7 +359,7 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
             R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
             R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
             R dist = R(1e9);
-            int id = trace_ray<R, COUNT, TRI_ONLY, NLDS>(sv, o, d, dist, st, &overflow, &wc);
+            int id = trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o, d, dist, st, &overflow, &wc);
             long long px = (long long)yl * a.width + x;
             ids[px] = id;
             if (t_out) t_out[px] = (double)dist;
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
                     R o2[3] = {(R)so.x, (R)so.y, (R)so.z};
                     R d2[3] = {(R)L.x, (R)L.y, (R)L.z};
                     R range = (R)(len - 1e-4);
-                    sid = trace_ray<R, COUNT, TRI_ONLY, NLDS>(sv, o2, d2, range, st, &overflow, &wc);
+                    sid = trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o2, d2, range, st, &overflow, &wc);
                     n_shadow++;
                 }
                 if (shadow_ids) shadow_ids[px] = sid;

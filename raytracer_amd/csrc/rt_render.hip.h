@@ -73,13 +73,13 @@ struct RenderArgs {
     int head_quirk, use_photon_map;
 };
 
-template <class R, bool TRI_ONLY, bool NLDS>
+template <class R, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits,
                                                                        unsigned long long shard_cap, RenderCounters* ctr, int cap, int n_nodes)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    const size_t node_bytes = NLDS ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
-    if (NLDS) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    const size_t node_bytes = MODE == rtk::TRAV_NODES ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
+    if (MODE == rtk::TRAV_NODES) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
     LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
                 R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
                 R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
                 R dist = R(1e9);
-                int id = rtk::trace_ray<R, false, TRI_ONLY, NLDS>(sv, o, d, dist, st, &ovf_stack);
+                int id = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack);
                 if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
                     double t = (double)dist;
                     rec.pos[0] = a.cam_pos[0] + dd.x * t; rec.pos[1] = a.cam_pos[1] + dd.y * t; rec.pos[2] = a.cam_pos[2] + dd.z * t;   // :821
@@ -221,14 +221,14 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
 }
 
 // Shoot for every queued ray of a level; hits become the next level's queue (main.cpp:190-199, 242-250).
-template <class R, bool TRI_ONLY, bool NLDS>
+template <class R, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneView<R> sv, RenderArgs a, int level, const RayRec* __restrict__ rays,
                                                                     HitRec* __restrict__ out, unsigned long long shard_cap, RenderCounters* ctr,
                                                                     int cap, int n_nodes)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    const size_t node_bytes = NLDS ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
-    if (NLDS) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    const size_t node_bytes = MODE == rtk::TRAV_NODES ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
+    if (MODE == rtk::TRAV_NODES) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
     LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0, n_secondary = 0;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
             R o[3] = {(R)ray.org[0], (R)ray.org[1], (R)ray.org[2]};
             R d[3] = {(R)ray.dir[0], (R)ray.dir[1], (R)ray.dir[2]};
             R dist = R(1e9);
-            int io = rtk::trace_ray<R, false, TRI_ONLY, NLDS>(sv, o, d, dist, st, &ovf_stack);
+            int io = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack);
             n_secondary++;
             double t = (double)dist;
             bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:193,245
