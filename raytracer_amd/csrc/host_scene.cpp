@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <array>
 
 #include "rt_math.h"
@@ -285,12 +286,33 @@ rtf::Prim<double> make_prim(const rtf::ObjShade& o, uint32_t id)
 
 struct Builder {
     const std::vector<Object>& objs;
-    std::vector<Box> box;                        // per object
-    std::vector<std::array<double, 3>> centre;   // BBox::Center, BVH.h:23-28
+    const std::vector<Box>& box;                        // per object
+    const std::vector<std::array<double, 3>>& centre;   // BBox::Center, BVH.h:23-28
     FlatBVH& out;
 
+    static uint32_t shift_ref(uint32_t ref, uint32_t node_off, uint32_t prim_off)
+    {
+        if (ref & rtf::LEAF_BIT) return ref + prim_off;     // the first-primitive field sits in the low bits
+        return ref + node_off;
+    }
+
+    // append a subtree built on its own (local numbering) behind what `out` already holds
+    uint32_t absorb(const FlatBVH& sub, uint32_t sub_ref)
+    {
+        const uint32_t node_off = (uint32_t)out.nodes.size(), prim_off = (uint32_t)out.prims.size();
+        for (rtf::Node<double> nd : sub.nodes) {
+            nd.c0 = shift_ref(nd.c0, node_off, prim_off);
+            nd.c1 = shift_ref(nd.c1, node_off, prim_off);
+            out.nodes.push_back(nd);
+        }
+        out.prims.insert(out.prims.end(), sub.prims.begin(), sub.prims.end());
+        out.n_leaves += sub.n_leaves;
+        out.depth = std::max(out.depth, sub.depth);
+        return shift_ref(sub_ref, node_off, prim_off);
+    }
+
     // returns the child reference and its box for a node holding `ids` (in the node's object order)
-    uint32_t build(std::vector<int>& ids, Box& node_box, int level)
+    uint32_t build(std::vector<int>& ids, Box& node_box, int level, int par_levels = 0)
     {
         if (level > out.depth) out.depth = level;
         if (ids.size() < 16) {                   // leaf: BVH.h:45, BVH.cpp:59
@@ -336,8 +358,22 @@ struct Builder {
         uint32_t me = (uint32_t)out.nodes.size();
         out.nodes.emplace_back();
         Box b0, b1;
-        uint32_t c0 = build(l, b0, level + 1);
-        uint32_t c1 = build(r, b1, level + 1);
+        uint32_t c0, c1;
+        if (par_levels > 0 && n >= 65536) {
+            // the two subtrees are independent: build them side by side, each into its own arrays, and
+            // append them in the order the serial build produces (node pre-order, leaf order)
+            FlatBVH lsub, rsub;
+            uint32_t lref = 0, rref = 0;
+            Builder lb{objs, box, centre, lsub}, rb{objs, box, centre, rsub};
+            std::thread other([&] { rref = rb.build(r, b1, level + 1, par_levels - 1); });
+            lref = lb.build(l, b0, level + 1, par_levels - 1);
+            other.join();
+            c0 = absorb(lsub, lref);
+            c1 = absorb(rsub, rref);
+        } else {
+            c0 = build(l, b0, level + 1);
+            c1 = build(r, b1, level + 1);
+        }
         rtf::Node<double>& nd = out.nodes[me];
         for (int i = 0; i < 3; i++) { nd.lo0[i] = b0.lo[i]; nd.hi0[i] = b0.hi[i]; nd.lo1[i] = b1.lo[i]; nd.hi1[i] = b1.hi[i]; }
         nd.c0 = c0;
@@ -353,20 +389,22 @@ void Scene::build_bvh()
 {
     bvh = FlatBVH{};
     std::vector<int> ids;
-    Builder b{objects, {}, {}, bvh};
-    b.box.resize(objects.size());
-    b.centre.resize(objects.size());
+    std::vector<Box> box(objects.size());
+    std::vector<std::array<double, 3>> centre(objects.size());
     for (size_t i = 0; i < objects.size(); i++) {
         const rtf::ObjShade& o = objects[i].sh;
         if (o.kind == rtf::PRIM_PLANE) {
             bvh.planes.push_back(make_prim(o, (uint32_t)i));
             continue;
         }
-        b.box[i] = object_box(o);
-        for (int ax = 0; ax < 3; ax++) b.centre[i][ax] = (b.box[i].hi[ax] + b.box[i].lo[ax]) / 2;
+        box[i] = object_box(o);
+        for (int ax = 0; ax < 3; ax++) centre[i][ax] = (box[i].hi[ax] + box[i].lo[ax]) / 2;
         ids.push_back((int)i);
     }
-    if (!ids.empty()) bvh.root_ref = b.build(ids, bvh.root_box, 0);
+    Builder b{objects, box, centre, bvh};
+    // large scenes: the top 4 levels fork (up to 16 subtrees side by side); the tree and its layout
+    // are those of the serial build
+    if (!ids.empty()) bvh.root_ref = b.build(ids, bvh.root_box, 0, 4);
     bvh.built = true;
 }
 

@@ -88,3 +88,22 @@ def test_no_cpu_fallback():
     with pytest.raises(rt.RtError) as e:
         rt.Context(0)
     assert e.value.code == -2
+
+
+def test_forked_bvh_build_equals_serial_tree():
+    """Scenes of >= 65536 objects build their top subtrees side by side; the flattened tree (topology,
+    object order, boxes) must be the one the oracle's serial restatement of BVH.cpp:57-96 gives."""
+    from oracle.bindings import Oracle
+
+    def fill(api):
+        for i in range(9):
+            for j in range(9):
+                api.load_obj(os.path.join(DATA, "teapot_normal.obj"), off=(0.0, i * 1.5, j * 1.5))
+        api.build_bvh()
+        return api
+    s, orc = fill(rt.Scene()), fill(Oracle())
+    assert s.size() == 81 * 992
+    rec, boxes = s.bvh_dump()
+    orec, oboxes = orc.bvh_dump()
+    assert eq(rec, orec)
+    assert eq(boxes, oboxes)
