@@ -396,18 +396,28 @@ __device__ __attribute__((noinline)) Cand walk_serial(PhotonMapView pm, float qx
 
 // k nearest photons within sqrt(r2) of one query held identically by all lanes.  Returns the
 // number of photons found; g_L.key / g_L.idx[0..count) is the set.
-__device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, int front_cap, Prof pf)
+// `hint` > 0: a bound known to contain at least k photons (from a neighbouring query, see
+// knn_collect); then steps 1's scan is skipped and the whole tree goes through the frontier.
+__device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, float hint, int front_cap,
+                                                 Prof pf)
 {
     WaveLds& L = g_L;
     const int lane = lane_id();
-    if (pm.n <= 0) return 0;
+    if (pm.n <= 0) return Cand{0, r2};
     Cand c{0, r2};               // candidates need d2 < bound (Kdtree.cpp:77,82: strict)
+    const bool hinted = hint > 0.f && hint < r2;
+    if (hinted) c.bound = hint;
 
     // ---- 1. near side down to a range of <= 2k photons, far sides onto the frontier
     int nf = 0;
     int lo = 0, hi = (int)pm.n;
     unsigned long long t0 = pf.now();
     const int limit = 2 * k > WAVE ? 2 * k : WAVE;
+    if (hinted) {
+        if (lane == 0) { L.f_lo[0] = 0; L.f_hi[0] = hi; L.f_d2[0] = 0.f; }
+        nf = 1;
+        lo = hi = 0;
+    }
     while (hi - lo > limit) {
         int mid = lo + (hi - lo) / 2;
         int ax = pm.axis[mid];
@@ -510,6 +520,39 @@ __device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, fl
         t0 = pf.now();
         c = select_k(c.count, k);
         pf.add(P_SELECT, pf.now() - t0); pf.add(P_N_SELECT, 1);
+    }
+    return c;
+}
+
+// State a wave carries from one query to the next.  Queries arrive in runs of neighbouring hit
+// points (one 8x8 pixel tile appends its requests together), and the k-th nearest distance obeys
+// the triangle inequality: r_k(q') <= r_k(q) + |q' - q|.  So a query that found its k photons hands
+// the next one a bound that already contains k photons -- no first scan, no intermediate selects,
+// and only the leaves that touch the final ball.
+struct Neighbour {
+    float x, y, z;
+    float radius;     // k-th nearest distance of the previous query; < 0: none
+};
+
+__device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, int front_cap, Prof pf,
+                                           Neighbour* nb = nullptr)
+{
+    float hint = 0.f;
+    if (nb && nb->radius >= 0.f) {
+        float dx = qx - nb->x, dy = qy - nb->y, dz = qz - nb->z;
+        float reach = nb->radius + sqrtf(dx * dx + dy * dy + dz * dz);
+        hint = reach * reach * 1.001f + 1e-12f;       // slack for the rounding of the distances
+    }
+    Cand c = knn_collect_from(pm, qx, qy, qz, k, r2, hint, front_cap, pf);
+    if (hint > 0.f && hint < r2 && c.count < k) {
+        // cannot happen in exact arithmetic; never return a short set because of a hint
+        __builtin_amdgcn_wave_barrier();
+        c = knn_collect_from(pm, qx, qy, qz, k, r2, 0.f, front_cap, pf);
+    }
+    if (nb) {
+        nb->x = qx; nb->y = qy; nb->z = qz;
+        // after the final select the bound is the k-th smallest distance; a set of fewer than k says nothing
+        nb->radius = c.count >= k ? sqrtf(c.bound) : -1.f;
     }
     return c.count;
 }
@@ -663,6 +706,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const rtq::Map map = rtq::map_units(cnt, shard_cap, 1);
     const uint32_t n = map.total;
     uint32_t q_end = 0;
+    Neighbour nb{0.f, 0.f, 0.f, -1.f};
     while (true) {
         uint32_t left = n > q_end ? n - q_end : 0;
         uint32_t want = left / (4u * gridDim.x);
@@ -677,7 +721,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             uint32_t first, n_shard;
             rtq::locate(map, q, 1, shard, first, n_shard);
             const GatherRec& r = recs[(unsigned long long)shard * shard_cap + first];
-            const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, gp.front_cap, pf);
+            const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, gp.front_cap, pf, &nb);
             __builtin_amdgcn_wave_barrier();
             double rgb[3];
             float md2;
