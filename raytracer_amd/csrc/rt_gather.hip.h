@@ -766,12 +766,19 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const Prof pf{prof};
     pf.init();
     __builtin_amdgcn_wave_barrier();
+    // runs of 8 consecutive queries per draw, like the gather kernel: neighbouring queries hand their bound on
+    Neighbour nb{0.f, 0.f, 0.f, -1.f};
+    unsigned long long q = 0, q_end = 0;
     while (true) {
-        unsigned long long q = 0;
-        if (lane == 0) q = atomicAdd(next, 1ull);
-        q = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q);
+        if (++q >= q_end) {
+            unsigned long long q0 = 0;
+            if (lane == 0) q0 = atomicAdd(next, 8ull);
+            q = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q0);
+            q_end = q + 8 < (unsigned long long)n ? q + 8 : (unsigned long long)n;
+            nb.radius = -1.f;
+        }
         if (q >= (unsigned long long)n) break;
-        const int count = knn_collect(pm, (float)pos[3 * q], (float)pos[3 * q + 1], (float)pos[3 * q + 2], gp.k, gp.r2, gp.front_cap, pf);
+        const int count = knn_collect(pm, (float)pos[3 * q], (float)pos[3 * q + 1], (float)pos[3 * q + 2], gp.k, gp.r2, gp.front_cap, pf, &nb);
         __builtin_amdgcn_wave_barrier();
         pf.add(P_QUERIES, 1);
         double rgb[3] = {0, 0, 0};

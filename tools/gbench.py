@@ -28,11 +28,23 @@ def main():
     ph = s.photons_get(0)
     ctx.photons_upload(ph)
     rng = np.random.default_rng(1)
-    pos = rng.uniform(-1, 1, (nq, 3))
-    face = rng.integers(0, 5, nq)
+    coherent = os.environ.get("GBENCH_COHERENT", "1") == "1"
+    if coherent:
+        # raster order over the five walls, like the requests of a frame (neighbouring queries are close)
+        side = int(np.sqrt(nq / 5))
+        u, v = np.meshgrid(np.linspace(-0.98, 0.98, side), np.linspace(-0.98, 0.98, side), indexing="ij")
+        nq = 5 * side * side
+        pos = np.zeros((nq, 3)); face = np.repeat(np.arange(5), side * side)
+        uu, vv = np.tile(u.ravel(), 5), np.tile(v.ravel(), 5)
+    else:
+        pos = rng.uniform(-1, 1, (nq, 3))
+        face = rng.integers(0, 5, nq)
     nrm = np.zeros((nq, 3))
     for f, (ax, val) in enumerate([(1, -1.0), (1, 1.0), (2, -1.0), (2, 1.0), (0, -1.0)]):
         m = face == f
+        if coherent:
+            others = [a for a in range(3) if a != ax]
+            pos[m, others[0]] = uu[m]; pos[m, others[1]] = vv[m]
         pos[m, ax] = val * 0.999
         nrm[m, ax] = -val
     col = np.full((nq, 3), 0.8)
