@@ -77,21 +77,40 @@ def main():
                                  band_rows=BAND if world > 1 else 0, n_parts=world, part=rank)
 
     params = make_params(prec)
-    # per-rank hit buffers in HBM: [0] primary ids, [1] shadow ids
-    buf = torch.empty((2, part_rows, w), dtype=torch.int32, device=dev)
-    recv = [torch.empty_like(buf) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # per-rank hit buffers in HBM: [0] primary ids, [1] shadow ids.  Two of them take turns when the
+    # frame is gathered, so that the gather of one step runs beside the kernel of the next.
+    comm = world > 1 or os.environ.get("BENCH_FORCE_COMM") == "1"     # the second form exercises the stream logic on one GPU
+    n_buf = 2 if comm else 1
+    bufs = [torch.empty((2, part_rows, w), dtype=torch.int32, device=dev) for _ in range(n_buf)]
+    buf = bufs[0]
+    recvs = [[torch.empty_like(buf) for _ in range(world)] for _ in range(n_buf)] if (world > 1 and rank == 0) else [None] * n_buf
     torch.cuda.synchronize()
 
     # The library launches on its own stream.  torch sees it as an external stream, so the events that
-    # bracket the timed region sit on the stream the kernels run on, and the RCCL gather (which
-    # orders itself against torch's current stream) queues behind each step's kernel without a
-    # host synchronisation.
+    # bracket the timed region sit on the stream the kernels run on.  The RCCL gather runs on a second
+    # stream: it waits for its step's kernel through an event, and the kernel that reuses a buffer
+    # waits for that buffer's gather -- no host synchronisation inside the timed region.
     ext = torch.cuda.ExternalStream(ctx.stream, device=dev)
+    comm_stream = torch.cuda.Stream(device=dev) if comm else None
+    gathered = [None] * n_buf      # event: the gather that read bufs[i] has finished
+    step_no = [0]
 
     def step(p, stats=False):
-        st = ctx.trace_primary_dev(cam, p, (0, part_rows), buf[0].data_ptr(), None, buf[1].data_ptr(), stats=stats)
-        if world > 1:
-            tiling.gather_to_rank0(buf, world, rank, dist, recv)   # RCCL: each rank sends its bands straight to rank 0
+        i = step_no[0] % n_buf
+        step_no[0] += 1
+        b = bufs[i]
+        if comm and gathered[i] is not None:
+            ext.wait_event(gathered[i])
+        st = ctx.trace_primary_dev(cam, p, (0, part_rows), b[0].data_ptr(), None, b[1].data_ptr(), stats=stats)
+        if comm:
+            traced = torch.cuda.Event()
+            traced.record(ext)
+            comm_stream.wait_event(traced)
+            with torch.cuda.stream(comm_stream):
+                tiling.gather_to_rank0(b, world, rank, dist, recvs[i])   # RCCL: each rank sends its bands straight to rank 0
+                done = torch.cuda.Event()
+                done.record(comm_stream)
+            gathered[i] = done
         return st
 
     def barrier():
@@ -102,19 +121,18 @@ def main():
 
     def timed(p, steps, warmup):
         """-> (rays of all ranks per step, max-over-ranks wall seconds, this rank's device ms per step)."""
-        with torch.cuda.stream(ext):
-            st = step(p, stats=True)                 # ray counts of one step (synchronises)
-            for _ in range(max(0, warmup - 1)):
-                step(p)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            barrier()
-            t0 = time.perf_counter()
-            e0.record(ext)
-            for _ in range(steps):
-                step(p)
-            e1.record(ext)
-            barrier()
-            dt = time.perf_counter() - t0
+        st = step(p, stats=True)                 # ray counts of one step (synchronises)
+        for _ in range(max(0, warmup - 1)):
+            step(p)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        t0 = time.perf_counter()
+        e0.record(ext)
+        for _ in range(steps):
+            step(p)
+        e1.record(ext)
+        barrier()
+        dt = time.perf_counter() - t0
         rays = torch.tensor([float(st.primary_rays + st.shadow_rays)], dtype=torch.float64, device=dev)
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
@@ -154,12 +172,14 @@ def main():
     if world == 1 and args.mesh == "teapot_normal.obj":
         from oracle.bindings import id_map_hash   # checker only
         step(make_params(rt.RT_F64), stats=True)
-        ids = buf[0].cpu().numpy().ravel()
+        torch.cuda.synchronize()
+        ids = bufs[(step_no[0] - 1) % n_buf][0].cpu().numpy().ravel()
         with open(os.path.join(GOLD, "idmap_hashes.txt")) as f:
             gold = {l.split()[0]: l.split()[1] for l in f}
         parity = {"f64_id_map_hash": id_map_hash(ids), "golden": gold["teapot_normal"], "ok": id_map_hash(ids) == gold["teapot_normal"]}
         step(make_params(rt.RT_F32), stats=True)
-        ids32 = buf[0].cpu().numpy().ravel()
+        torch.cuda.synchronize()
+        ids32 = bufs[(step_no[0] - 1) % n_buf][0].cpu().numpy().ravel()
         parity["f32_id_mismatch_fraction"] = float((ids32 != ids).mean())
 
     traffic = valu_busy = None
@@ -192,7 +212,8 @@ def main():
         "config": {
             "workload": f"{args.mesh} + Cornell box ({scene.size()} triangles, BVH depth {scene.bvh_depth()}), {w}x{h}, primary + 1 shadow ray per hit",
             "rays_per_step": int(rays_per_step),
-            "parallelism": f"rows in bands of {tiling.BAND} over {world} GPU(s), scene replicated, RCCL gather to rank 0" if world > 1 else "1 GPU",
+            "parallelism": f"rows in bands of {tiling.BAND} over {world} GPU(s), scene replicated, RCCL gather to rank 0 overlapped with the next step's kernel"
+                           if world > 1 else "1 GPU",
         },
         "roofline": {
             "bound": "hbm",
