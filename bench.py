@@ -247,49 +247,84 @@ def main():
         dist.destroy_process_group()
 
 
+def _shadow_rays(org, d, ids, t):
+    """Occlusion queries toward the light for the hit pixels, as the device kernel forms them."""
+    light = np.array([0.1, 0.2, 0.0])
+    hit = ids >= 0
+    P = org[hit] + d[hit] * t[hit][:, None]
+    Lv = light - P
+    ln = np.sqrt(Lv[:, 0] * Lv[:, 0] + Lv[:, 1] * Lv[:, 1] + Lv[:, 2] * Lv[:, 2])
+    L = Lv / ln[:, None]
+    return P + L * 1e-4, L, ln - 1e-4
+
+
+def _time_cpu(shoot, org, d, seconds, w, h):
+    """shoot(org, dir, max_dist) -> (ids, t).  Frames of primary + shadow rays until `seconds` have passed;
+    only the time inside the traversal calls counts (ray set-up in numpy does not)."""
+    frames = rays = 0
+    trav = 0.0
+    t0 = time.perf_counter()
+    while True:
+        a = time.perf_counter()
+        ids, t = shoot(org, d, 1e9)
+        trav += time.perf_counter() - a
+        so, L, rng = _shadow_rays(org, d, ids, t)
+        a = time.perf_counter()
+        shoot(so, L, rng)
+        trav += time.perf_counter() - a
+        frames += 1
+        rays += len(ids) + len(so)
+        if time.perf_counter() - t0 > seconds:
+            return rays / trav / 1e6, frames
+
+
 def cpu_baseline(args, w, h):
-    """The CPU oracle (f64 restatement of the reference traversal, validated bit-exact against the
-    compiled reference) timed on this host: same scene, same frame, primary + shadow rays."""
-    from oracle.bindings import Oracle
+    """CPU side of the comparison on this host's cores: same scene, same frame, primary + shadow rays.
+    Where the compiled reference (oracle/_ref, built from the reference's own sources) is present, its
+    BVH::Shoot is timed from `threads` host threads (kind "reference"); the f64 CPU restatement, validated
+    bit-exact against it, is timed the same way and is the figure when the reference build is absent."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle.bindings import Oracle, Reference, have_reference
     threads = min(16, os.cpu_count() or 1)
     orc = Oracle()
     orc.load_obj(os.path.join(DATA, args.mesh))
     orc.add_cornell()
     orc.build_bvh()
     org, d = orc.primary_rays(w, h, CAM)
-    light = np.array([0.1, 0.2, 0.0])
-    frames = 0
-    rays = 0
-    trav = 0.0   # seconds inside the traversal calls only (ray set-up in numpy is not counted)
-    t0 = time.perf_counter()
-    while True:
-        a = time.perf_counter()
-        ids, t = orc.shoot_mt(org, d, threads=threads)
-        trav += time.perf_counter() - a
-        hit = ids >= 0
-        P = org[hit] + d[hit] * t[hit][:, None]
-        Lv = light - P
-        ln = np.sqrt(Lv[:, 0] * Lv[:, 0] + Lv[:, 1] * Lv[:, 1] + Lv[:, 2] * Lv[:, 2])
-        L = Lv / ln[:, None]
-        so = P + L * 1e-4
-        rng = ln - 1e-4
-        a = time.perf_counter()
-        orc.shoot_mt(so, L, rng, threads=threads)
-        trav += time.perf_counter() - a
-        frames += 1
-        rays += len(ids) + int(hit.sum())
-        if time.perf_counter() - t0 > args.cpu_seconds:
-            break
-    dt = trav
-    return {
-        "value": round(rays / dt / 1e6, 3),
+    have_ref = have_reference()
+    budget = args.cpu_seconds / (2 if have_ref else 1)
+    port, port_frames = _time_cpu(lambda o, dd, m: orc.shoot_mt(o, dd, m, threads=threads), org, d, budget, w, h)
+    out = {
+        "value": round(port, 3),
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{frames} frame(s) of the same {w}x{h} workload (primary + shadow), f64 CPU restatement, {threads} threads; "
+        "sample": f"{port_frames} frame(s) of the same {w}x{h} workload (primary + shadow), f64 CPU restatement, {threads} threads; "
                   "traversal time only",
         "cpu_count": os.cpu_count(),
     }
+    if have_ref:
+        try:
+            ref = Reference()
+            ref.load_obj(os.path.join(DATA, args.mesh))
+            ref.add_cornell()
+            ref.build_bvh()
+            pool = ThreadPoolExecutor(threads)
+
+            def shoot(o, dd, m):     # BVH::Shoot is const and lock-free; ctypes releases the GIL inside the call
+                n = len(o)
+                cuts = [n * i // threads for i in range(threads + 1)]
+                md = np.full(n, m) if np.isscalar(m) else m
+                parts = list(pool.map(lambda i: ref.shoot(o[cuts[i]:cuts[i + 1]], dd[cuts[i]:cuts[i + 1]], md[cuts[i]:cuts[i + 1]]), range(threads)))
+                return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+            val, frames = _time_cpu(shoot, org, d, budget, w, h)
+            out.update(value=round(val, 3), kind="reference", port_value=round(port, 3),
+                       sample=f"{frames} frame(s) of the same {w}x{h} workload (primary + shadow) through the compiled reference's BVH::Shoot, "
+                              f"{threads} host threads; traversal time only (the f64 restatement reaches port_value)")
+        except Exception as e:     # the checker's build is optional on the GPU box
+            out["reference_error"] = str(e)[:200]
+    return out
 
 
 if __name__ == "__main__":
