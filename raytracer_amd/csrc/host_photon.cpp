@@ -265,11 +265,12 @@ void build_photon_map(const double* photons9, int64_t n, FlatPhotonMap& out, int
     while ((1 << levels) < threads) levels++;
     KdBuild kb{photons9, out.order, out.axis};
     if (n > 0) kb.build(0, n, levels);
-    out.pos.resize((size_t)n * 3);
+    out.pos.resize((size_t)n * 4);
     out.aux.resize((size_t)n * 6);
     for (int64_t i = 0; i < n; i++) {
         const double* p = photons9 + (size_t)out.order[i] * 9;
-        for (int c = 0; c < 3; c++) out.pos[(size_t)i * 3 + c] = (float)p[c];
+        for (int c = 0; c < 3; c++) out.pos[(size_t)i * 4 + c] = (float)p[c];
+        out.pos[(size_t)i * 4 + 3] = (float)out.axis[i];
         for (int c = 0; c < 6; c++) out.aux[(size_t)i * 6 + c] = (float)p[3 + c];
     }
 }

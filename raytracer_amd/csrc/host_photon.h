@@ -34,7 +34,8 @@ void emit_photons(const Scene& s, int64_t n_emit, const double* light_pos, uint3
 // right one (mid, hi); ranges of <= LEAF photons are leaves scanned by a whole wave.
 struct FlatPhotonMap {
     static constexpr int LEAF = 64;
-    std::vector<float> pos;        // 3 per photon, tree order
+    std::vector<float> pos;        // 4 per photon, tree order: x, y, z and the split axis (as a float 0/1/2) of the node
+                                   // whose pivot this photon is -- one aligned 16-byte record per photon
     std::vector<float> aux;        // 6 per photon: power rgb, dir xyz
     std::vector<uint8_t> axis;     // split axis of the node whose pivot this photon is
     std::vector<int32_t> order;    // tree position -> index in the caller's array

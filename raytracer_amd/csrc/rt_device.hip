@@ -713,12 +713,10 @@ int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photo
     rth::build_photon_map(photons, n, fm);
     if ((rc = upload(ctx->ph_pos[which], fm.pos, ctx->stream))) return rc;
     if ((rc = upload(ctx->ph_aux[which], fm.aux, ctx->stream))) return rc;
-    if ((rc = upload(ctx->ph_axis[which], fm.axis, ctx->stream))) return rc;
     if ((rc = upload(ctx->ph_order[which], fm.order, ctx->stream))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->pm[which].pos = (const float*)ctx->ph_pos[which].p;
+    ctx->pm[which].pos = (const float4*)ctx->ph_pos[which].p;
     ctx->pm[which].aux = (const float*)ctx->ph_aux[which].p;
-    ctx->pm[which].axis = (const uint8_t*)ctx->ph_axis[which].p;
     ctx->pm[which].order = (const int*)ctx->ph_order[which].p;
     ctx->pm[which].n = n;
     return RT_OK;

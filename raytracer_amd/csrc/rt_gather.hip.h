@@ -36,9 +36,8 @@ constexpr int STACK = 48;        // > log2(2^31 / 64) levels
 constexpr int FRONT = 256;       // frontier capacity (ranges); beyond it subtrees are walked serially
 
 struct PhotonMapView {
-    const float* pos;            // 3 per photon, tree order
+    const float4* pos;           // per photon, tree order: x, y, z, split axis of the node whose pivot it is (0/1/2 as a float)
     const float* aux;            // 6 per photon: power rgb, dir xyz
-    const uint8_t* axis;
     const int* order;            // tree position -> index in the caller's photon array
     long long n;
 };
@@ -297,19 +296,16 @@ __device__ __attribute__((noinline)) Cand scan_steps(PhotonMapView pm, float qx,
         float px[FLIGHT], py[FLIGHT], pz[FLIGHT];
         int id[FLIGHT];
         bool valid[FLIGHT];
+        // every load is unconditional (step and lane clamped to valid ones): a load inside a divergent
+        // branch is waited for at the branch's join, which would serialise the round trips
 #pragma unroll
         for (int u = 0; u < FLIGHT; u++) {
-            valid[u] = false;
-            id[u] = 0;
-            if (g + u < n_steps) {
-                int lo = L.c_lo[g + u], n = L.c_n[g + u];
-                valid[u] = lane < n;
-                id[u] = lo + lane;
-                if (valid[u]) {
-                    const float* p = pm.pos + 3 * (size_t)id[u];
-                    px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
-                }
-            }
+            const int step = g + u < n_steps ? g + u : n_steps - 1;
+            const int lo = L.c_lo[step], n = L.c_n[step];
+            valid[u] = g + u < n_steps && lane < n;
+            id[u] = lo + (lane < n ? lane : (n > 0 ? n - 1 : 0));     // n >= 1 for every listed step
+            const float4 p = pm.pos[id[u]];
+            px[u] = p.x; py[u] = p.y; pz[u] = p.z;
         }
 #pragma unroll
         for (int v = 0; v < FLIGHT; v += GROUP) {
@@ -370,8 +366,9 @@ __device__ __attribute__((noinline)) Cand walk_serial(PhotonMapView pm, float qx
         have = false;
         while (hi - lo > WAVE) {
             int mid = lo + (hi - lo) / 2;
-            int ax = pm.axis[mid];
-            float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
+            const float4 pv = pm.pos[mid];
+            const int ax = (int)pv.w;
+            float px = pv.x, py = pv.y, pz = pv.z;
             float dx = qx - px, dy = qy - py, dz = qz - pz;
             float d2 = dx * dx + dy * dy + dz * dz;
             make_room(c, k, WAVE, pf);
@@ -420,8 +417,9 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
     }
     while (hi - lo > limit) {
         int mid = lo + (hi - lo) / 2;
-        int ax = pm.axis[mid];
-        float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
+        const float4 pv = pm.pos[mid];
+        const int ax = (int)pv.w;
+        float px = pv.x, py = pv.y, pz = pv.z;
         float dx = qx - px, dy = qy - py, dz = qz - pz;
         float d2 = dx * dx + dy * dy + dz * dz;
         append(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119); < 32 of these
@@ -450,7 +448,10 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
     }
     __builtin_amdgcn_wave_barrier();
 
-    // ---- 2. frontier rounds
+    // ---- 2. frontier rounds.  Leaves found on the way are listed and scanned together, 16 at a time in
+    // flight, when the list is full or the frontier is empty: one memory round trip per batch of
+    // leaves instead of one per round.
+    int n_pend = 0;
     while (nf > 0) {
         t0 = pf.now();
         const int take = nf < WAVE ? nf : WAVE;
@@ -466,8 +467,9 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
         float dd = 0.f, d2 = 3.0e38f;
         if (is_inner) {
             mid = rlo + (rhi - rlo) / 2;
-            int ax = pm.axis[mid];
-            float px = pm.pos[3 * (size_t)mid], py = pm.pos[3 * (size_t)mid + 1], pz = pm.pos[3 * (size_t)mid + 2];
+            const float4 pv = pm.pos[mid];
+            const int ax = (int)pv.w;
+            float px = pv.x, py = pv.y, pz = pv.z;
             float dx = qx - px, dy = qy - py, dz = qz - pz;
             d2 = dx * dx + dy * dy + dz * dz;
             float split = ax == 0 ? px : (ax == 1 ? py : pz);
@@ -483,12 +485,21 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
         const unsigned long long m_far = __ballot(push_far), m_near = __ballot(push_near), m_leaf = __ballot(is_leaf);
         const int n_far = __builtin_popcountll(m_far), n_near = __builtin_popcountll(m_near), n_leaf = __builtin_popcountll(m_leaf);
         __builtin_amdgcn_wave_barrier();
+        const bool fits = nf + n_far + n_near <= front_cap;
+        if (n_pend > 0 && (n_pend + n_leaf > WAVE || !fits)) {
+            // (the serial walk of a full frontier uses the leaf list as its own scratch)
+            unsigned long long ts = pf.now();
+            c = scan_steps(pm, qx, qy, qz, n_pend, k, c, pf);
+            pf.add(P_LEAVES, pf.now() - ts); pf.add(P_N_LEAVES, n_pend);
+            n_pend = 0;
+            __builtin_amdgcn_wave_barrier();
+        }
         if (is_leaf) {
-            int r = (int)prefix_rank(m_leaf);
+            int r = n_pend + (int)prefix_rank(m_leaf);
             L.c_lo[r] = rlo;
             L.c_n[r] = rhi - rlo;
         }
-        const bool fits = nf + n_far + n_near <= front_cap;
+        n_pend += n_leaf;
         if (fits) {
             // far sides below near sides: the near sides are taken first
             if (push_far) { int p = nf + (int)prefix_rank(m_far); L.f_lo[p] = flo; L.f_hi[p] = fhi; L.f_d2[p] = dd; }
@@ -499,10 +510,14 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
         __builtin_amdgcn_wave_barrier();
         t1 = pf.now();
         pf.add(P_ROUNDS, t1 - t0); pf.add(P_N_ROUNDS, 1);
-        if (n_leaf > 0) c = scan_steps(pm, qx, qy, qz, n_leaf, k, c, pf);
-        pf.add(P_LEAVES, pf.now() - t1); pf.add(P_N_LEAVES, n_leaf);
         if (!fits) {
             // frontier full: walk this round's children serially instead, lane by lane
+            if (n_pend > 0) {
+                c = scan_steps(pm, qx, qy, qz, n_pend, k, c, pf);
+                pf.add(P_N_LEAVES, n_pend);
+                n_pend = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
             unsigned long long todo = m_far | m_near;
             while (todo) {
                 int src = __builtin_ctzll(todo);
@@ -514,6 +529,11 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
             }
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (n_pend > 0) {
+        t0 = pf.now();
+        c = scan_steps(pm, qx, qy, qz, n_pend, k, c, pf);
+        pf.add(P_LEAVES, pf.now() - t0); pf.add(P_N_LEAVES, n_pend);
     }
     if (c.count > k) {
         __builtin_amdgcn_wave_barrier();
@@ -605,13 +625,11 @@ __device__ void estimate_raw(const PhotonMapView& pm, int count, const double* n
         for (int u = 0; u < UNR; u++) {
             int j = base + u * WAVE + lane;
             valid[u] = j < count;
-            dsq[u] = 0.f;
-            if (valid[u]) {
-                dsq[u] = L.key[j];
-                const float* src = pm.aux + 6 * (size_t)L.idx[j];
+            const int jj = valid[u] ? j : count - 1;      // unconditional fetches (clamped): all in flight together
+            dsq[u] = L.key[jj];
+            const float* src = pm.aux + 6 * (size_t)L.idx[jj];
 #pragma unroll
-                for (int c = 0; c < 6; c++) a[u][c] = src[c];
-            }
+            for (int c = 0; c < 6; c++) a[u][c] = src[c];
         }
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
@@ -678,8 +696,8 @@ __device__ void volume_step(const PhotonMapView& vm, int count, const float* hit
         if (ok > far_key || (ok == far_key && oi < far_idx)) { far_key = ok; far_idx = oi; }
     }
     p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
-    const float* fp = vm.pos + 3 * (size_t)far_idx;
-    float dx = hit_pos[0] - fp[0], dy = hit_pos[1] - fp[1], dz = hit_pos[2] - fp[2];
+    const float4 fp = vm.pos[far_idx];
+    float dx = hit_pos[0] - fp.x, dy = hit_pos[1] - fp.y, dz = hit_pos[2] - fp.z;
     float m = dx * dx + dy * dy + dz * dz;        // maxDistSqr, main.cpp:317, 353
     double scale = 1.0 / (e_pass * photon_num / 8 * 3.1415926 * m * sqrtf(m));   // main.cpp:332, 371
     sss[0] += p0 * scale; sss[1] += p1 * scale; sss[2] += p2 * scale;
