@@ -181,6 +181,14 @@ def main():
         torch.cuda.synchronize()
         ids32 = bufs[(step_no[0] - 1) % n_buf][0].cpu().numpy().ravel()
         parity["f32_id_mismatch_fraction"] = float((ids32 != ids).mean())
+        # the float instantiation against the oracle's single-precision restatement of the same traversal
+        from oracle.bindings import Oracle
+        orc = Oracle()
+        orc.load_obj(os.path.join(DATA, args.mesh))
+        orc.add_cornell()
+        orc.build_bvh()
+        o_, d_ = orc.primary_rays(w, h, CAM)
+        parity["f32_ids_equal_f32_restatement"] = bool(np.array_equal(orc.shoot_f32(o_, d_, threads=min(16, os.cpu_count() or 1))[0], ids32))
 
     traffic = valu_busy = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

@@ -197,6 +197,13 @@ class Oracle(_Common):
         self.lib.orc_shoot_mt(self.h, c_l(n), _dp(org), _dp(d), _dp(dist), _ip(ids), c_i(threads))
         return ids, dist
 
+    def shoot_f32(self, org, d, max_dist=1e9, threads=8):
+        org = _f64(org); d = _f64(d); n = org.shape[0]
+        dist = np.full(n, max_dist, dtype=np.float64) if np.isscalar(max_dist) else _f64(max_dist).copy()
+        ids = np.zeros(n, np.int32)
+        self.lib.orc_shoot_f32(self.h, c_l(n), _dp(org), _dp(d), _dp(dist), _ip(ids), c_i(threads))
+        return ids, dist
+
     def shoot_stats(self, org, d, max_dist=1e9):
         org = _f64(org); d = _f64(d)
         c = np.zeros(4, np.int64)

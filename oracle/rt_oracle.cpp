@@ -1056,6 +1056,155 @@ void orc_shoot_mt(const orc_scene* s, int64_t n, const double* org, const double
         });
     for (auto& x : th) x.join();
 }
+// ---------------------------------------------------------------- single-precision restatement
+// The same traversal (BVH.cpp:5-24, 108-179) and primitive tests (Triangle.h:260-279, Sphere.h:44-90,
+// Plane.h:26-39) with every quantity rounded to float and every operation done in float, on the
+// SAME tree: boxes are the double boxes rounded to float, a triangle is stored as A, B - A, C - A
+// (differences taken in double, then rounded), rays are the double rays rounded.  This is what a
+// float build of the reference computes on float-rounded scene data; it checks the float
+// instantiation of the device kernels bit for bit.
+namespace {
+struct PrimF { int kind; float a[3], e1[3], e2[3]; float radius; float pdistance; };
+struct SceneF {
+    std::vector<PrimF> prims;
+    std::vector<float> box;   // 6 per node: [axis][lo, hi]
+};
+
+float box_intersect_f(const float* bx, const float* o, const float* d, float current_best)
+{
+    float t0 = 0.f, t1 = current_best;
+    for (int i = 0; i < 3; i++) {
+        float inv_ray = 1.f / d[i];
+        float far_t = (bx[2 * i] - o[i]) * inv_ray;
+        float near_t = (bx[2 * i + 1] - o[i]) * inv_ray;
+        if (near_t > far_t) std::swap(near_t, far_t);
+        t0 = near_t > t0 ? near_t : t0;
+        t1 = far_t > t1 ? t1 : far_t;
+        if (t0 > t1) return -1.f;
+    }
+    return t0;
+}
+
+float prim_intersect_f(const PrimF& p, const float* o, const float* d)
+{
+    if (p.kind == TRI) {
+        const float *A = p.a, *e1 = p.e1, *e2 = p.e2;
+        float qx = d[1] * e2[2] - d[2] * e2[1];
+        float qy = d[2] * e2[0] - d[0] * e2[2];
+        float qz = d[0] * e2[1] - d[1] * e2[0];
+        float a = e1[0] * qx + e1[1] * qy + e1[2] * qz;
+        if (std::fabs(a) < 0.00001f) return -1.f;
+        float f = 1.f / a;
+        float sx = o[0] - A[0], sy = o[1] - A[1], sz = o[2] - A[2];
+        float u = f * (sx * qx + sy * qy + sz * qz);
+        if (u < 0.f) return -1.f;
+        float rx = sy * e1[2] - sz * e1[1];
+        float ry = sz * e1[0] - sx * e1[2];
+        float rz = sx * e1[1] - sy * e1[0];
+        float v = f * (d[0] * rx + d[1] * ry + d[2] * rz);
+        if (v < 0.f || u + v > 1.f) return -1.f;
+        return f * (rx * e2[0] + ry * e2[1] + rz * e2[2]);
+    }
+    if (p.kind == SPHERE) {
+        const float* c = p.a;
+        float ox = o[0] + 0.1f * d[0], oy = o[1] + 0.1f * d[1], oz = o[2] + 0.1f * d[2];
+        float b = (2.f * (ox - c[0]) * d[0]) + (2.f * (oy - c[1]) * d[1]) + (2.f * (oz - c[2]) * d[2]);
+        float cc = (ox - c[0]) * (ox - c[0]) + (oy - c[1]) * (oy - c[1]) + (oz - c[2]) * (oz - c[2]) - p.radius * p.radius;
+        float disc = b * b - 4.f * cc;
+        if (disc > 0.f) {
+            float root_1 = ((-1.f * b - std::sqrt(disc)) / 2.f) - 0.000001f;
+            if (root_1 > 0.f) return root_1;
+            return ((-1.f * b + std::sqrt(disc) - b) / 2.f) - 0.000001f;
+        }
+        return -1.f;
+    }
+    const float* n = p.a;
+    float a = d[0] * n[0] + d[1] * n[1] + d[2] * n[2];
+    if (a == 0.f) return -1.f;
+    float px = o[0] + (-(n[0] * p.pdistance)), py = o[1] + (-(n[1] * p.pdistance)), pz = o[2] + (-(n[2] * p.pdistance));
+    float b = n[0] * px + n[1] * py + n[2] * pz;
+    return -1.f * b / a;
+}
+
+int shoot_node_f(const orc_scene* s, const SceneF& f, int n, const float* o, const float* d, float& distance)
+{
+    const Node& nd = s->nodes[n];
+    if (box_intersect_f(&f.box[6 * (size_t)n], o, d, distance) < 0) return -1;
+    int result = -1;
+    for (int obj : nd.objs) {
+        float t = prim_intersect_f(f.prims[obj], o, d);
+        if (t >= 0 && t < distance) { result = obj; distance = std::min(distance, t); }
+    }
+    if (nd.child[0] < 0) return result;
+    float td[2];
+    for (int i = 0; i < 2; i++) td[i] = box_intersect_f(&f.box[6 * (size_t)nd.child[i]], o, d, distance);
+    int first = td[0] < td[1] ? 0 : 1;
+    int rc = shoot_node_f(s, f, nd.child[first], o, d, distance);
+    if (rc >= 0) result = rc;
+    rc = shoot_node_f(s, f, nd.child[1 - first], o, d, distance);
+    if (rc >= 0) result = rc;
+    return result;
+}
+
+SceneF make_scene_f(const orc_scene* s)
+{
+    SceneF f;
+    f.prims.resize(s->prims.size());
+    for (size_t i = 0; i < s->prims.size(); i++) {
+        const Prim& p = s->prims[i];
+        PrimF& q = f.prims[i];
+        q.kind = p.kind;
+        q.radius = q.pdistance = 0.f;
+        for (int c = 0; c < 3; c++) q.a[c] = q.e1[c] = q.e2[c] = 0.f;
+        if (p.kind == TRI) {
+            V3 e1 = vsub(p.B, p.A), e2 = vsub(p.C, p.A);
+            for (int c = 0; c < 3; c++) { q.a[c] = (float)p.A[c]; q.e1[c] = (float)e1[c]; q.e2[c] = (float)e2[c]; }
+        } else if (p.kind == SPHERE) {
+            for (int c = 0; c < 3; c++) q.a[c] = (float)p.center[c];
+            q.radius = (float)p.radius;
+        } else {
+            for (int c = 0; c < 3; c++) q.a[c] = (float)p.pnormal[c];
+            q.pdistance = (float)p.pdistance;
+        }
+    }
+    f.box.resize(6 * s->nodes.size());
+    for (size_t n = 0; n < s->nodes.size(); n++)
+        for (int ax = 0; ax < 3; ax++) {
+            f.box[6 * n + 2 * ax] = (float)s->nodes[n].box.d[ax][0];
+            f.box[6 * n + 2 * ax + 1] = (float)s->nodes[n].box.d[ax][1];
+        }
+    return f;
+}
+}  // namespace
+
+// dist is in/out like BVH::Shoot's `distance` (rounded to float on the way in, widened on the way out for hits)
+void orc_shoot_f32(const orc_scene* s, int64_t n, const double* org, const double* dir, double* dist, int32_t* ids, int32_t threads)
+{
+    const SceneF f = make_scene_f(s);
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++)
+        th.emplace_back([&, t]() {
+            int64_t a = n * t / threads, b = n * (t + 1) / threads;
+            for (int64_t i = a; i < b; i++) {
+                float o[3] = {(float)org[3 * i], (float)org[3 * i + 1], (float)org[3 * i + 2]};
+                float d[3] = {(float)dir[3 * i], (float)dir[3 * i + 1], (float)dir[3 * i + 2]};
+                float distance = (float)dist[i];
+                int result = -1;
+                if (!(d[0] != d[0])) {
+                    if (!s->nodes.empty() && !(box_intersect_f(&f.box[0], o, d, distance) < 0)) result = shoot_node_f(s, f, 0, o, d, distance);
+                    for (int pl : s->planes) {
+                        float tt = prim_intersect_f(f.prims[pl], o, d);
+                        if (tt >= 0 && tt < distance) { result = pl; distance = std::min(distance, tt); }
+                    }
+                }
+                ids[i] = result;
+                if (result >= 0) dist[i] = (double)distance;
+            }
+        });
+    for (auto& x : th) x.join();
+}
+
 void orc_shoot_stats(const orc_scene* s, int64_t n, const double* org, const double* dir, double max_dist, int64_t* counters)
 {
     Counters c;

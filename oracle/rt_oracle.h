@@ -58,6 +58,8 @@ void orc_bvh_dump_copy(orc_scene*, int32_t* rec, double* boxes);
 void orc_shoot(const orc_scene*, int64_t n, const double* org, const double* dir, double* dist, int32_t* ids);
 void orc_shoot_mt(const orc_scene*, int64_t n, const double* org, const double* dir, double* dist, int32_t* ids, int32_t threads);
 /* per-ray work counters of the traversal: slab calls, inner nodes entered, primitive tests */
+/* the same traversal in single precision on float-rounded scene data (checks the float device instantiation) */
+void orc_shoot_f32(const orc_scene*, int64_t n, const double* org, const double* dir, double* dist, int32_t* ids, int32_t threads);
 void orc_shoot_stats(const orc_scene*, int64_t n, const double* org, const double* dir, double max_dist, int64_t* counters);
 void orc_brute_force(const orc_scene*, int64_t n, const double* org, const double* dir, double* dist, int32_t* ids);
 

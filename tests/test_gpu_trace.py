@@ -175,3 +175,59 @@ def test_instanced_grid_deep_tree(gpu_ctx):
     rid, rdist = orc.shoot(o, dd)
     assert np.array_equal(gid, rid)
     assert np.array_equal(gt, rdist)
+
+
+def _mixed_scene(api):
+    r2 = np.random.default_rng(21)
+    for i in range(60):
+        A, C, B = r2.uniform(-1, 1, (3, 3))
+        api.add_triangle(A, C, B, (0.3, 0.6, 0.9, 0.0), 1.5)
+    for i in range(30):
+        api.add_sphere(r2.uniform(-0.8, 0.8, 3), float(r2.uniform(0.05, 0.4)), (1, 1, 1, 0.9), 1.5)
+    api.add_plane((0.0, 1.0, 0.0), -1.0, (0.5, 0.5, 0.5, 0))
+    api.build_bvh()
+    return api
+
+
+def test_f32_instantiation_bit_exact(gpu_ctx, scenes):
+    """The float instantiation of the kernels against the oracle's single-precision restatement (same
+    tree, scene data and rays rounded to float, every operation in float): ids and t bit for bit --
+    primary frames, random / bounded / axis-parallel rays (NaN paths), spheres and planes, a deep tree."""
+    for tag in ["teapot_normal", "water"]:
+        gpu_ctx.upload(scenes[tag])
+        orc = build_scene(Oracle(), tag + ".obj")
+        w, h = 640, 360
+        ids, t, _, _ = gpu_ctx.trace_primary(rt.look_at(CAM[:3], CAM[3:]), rt.default_params(width=w, height=h, precision=rt.RT_F32))
+        org, d = orc.primary_rays(w, h, CAM)
+        oid, ot = orc.shoot_f32(org, d)
+        assert eq(ids, oid), tag
+        assert eq(np.where(ids >= 0, t, 1e9), ot), tag
+        g = golden(f"rays_{tag}.npz")
+        for o_, d_, m_ in [(g["org"], g["dir"], 1e9), (g["org"], g["dir"], g["max_dist"]), (g["org_axis"], g["dir_axis"], 1e9)]:
+            gid, gt = gpu_ctx.trace_closest(o_, d_, m_, precision=rt.RT_F32)
+            rid, rdist = orc.shoot_f32(o_, d_, m_)
+            assert eq(gid, rid), tag
+            # misses keep the caller's double range untouched on both sides
+            assert eq(gt, rdist), tag
+    s, orc = _mixed_scene(rt.Scene()), _mixed_scene(Oracle())
+    gpu_ctx.upload(s)
+    rng = np.random.default_rng(4)
+    org = rng.uniform(-1.5, 1.5, (20000, 3)); d = rng.normal(size=(20000, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    gid, gt = gpu_ctx.trace_closest(org, d, precision=rt.RT_F32)
+    rid, rdist = orc.shoot_f32(org, d)
+    assert eq(gid, rid) and eq(gt, rdist)
+
+    def grid(api):
+        for i in range(7):
+            for j in range(7):
+                api.load_obj(os.path.join(DATA, "teapot_normal.obj"), off=(0.0, i * 1.5, j * 1.5))
+        api.build_bvh()
+        return api
+    s, orc = grid(rt.Scene()), grid(Oracle())
+    gpu_ctx.upload(s)
+    cam_v = np.array([9.0, 4.5, 4.5, 0.0, 4.5, 4.5])
+    ids, t, _, _ = gpu_ctx.trace_primary(rt.look_at(cam_v[:3], cam_v[3:]), rt.default_params(width=320, height=200, precision=rt.RT_F32))
+    org, d = orc.primary_rays(320, 200, cam_v)
+    oid, ot = orc.shoot_f32(org, d)
+    assert eq(ids, oid) and eq(np.where(ids >= 0, t, 1e9), ot)

@@ -211,3 +211,18 @@ def test_subsurface_shading():
     rgb = np.zeros((64 * 64, 3))
     rgb[hit] = orc.get_color_at(pos, d[hit], ids[hit], 1)
     assert eq(rgb.reshape(64, 64, 3), g["rgb"])
+
+
+def test_single_precision_restatement_tracks_the_double_one():
+    """orc_shoot_f32 (float arithmetic on float-rounded data, same tree): ids agree with the double
+    traversal except near silhouettes, t to float accuracy; NaN directions miss in both."""
+    orc = build_scene(Oracle(), "teapot_normal.obj")
+    org, d = orc.primary_rays(320, 180, CAM)
+    i64, t64 = orc.shoot(org, d)
+    i32, t32 = orc.shoot_f32(org, d)
+    assert (i64 != i32).mean() < 0.01
+    same = (i64 == i32) & (i64 >= 0)
+    assert np.abs(t64[same] - t32[same]).max() < 1e-4
+    d[::7] = np.nan
+    i32, t32 = orc.shoot_f32(org, d)
+    assert (i32[::7] == -1).all() and (t32[::7] == 1e9).all()
