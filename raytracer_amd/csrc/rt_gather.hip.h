@@ -84,6 +84,8 @@ struct Prof {
 struct Cand {
     int count;       // entries in g_L.key / g_L.idx
     float bound;     // candidates need d2 < bound
+    int tight;       // the keys reach up to the bound (a select or a neighbour's hint set it): the
+                     // select may bin over [0, bound] without looking for the largest key first
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -158,21 +160,24 @@ __device__ uint32_t radix_threshold(int count, int k, int& want)
 // leaves only a handful of entries in the bin that holds the k-th smallest; those are ranked
 // directly.  (Bins are monotonic in the key, so every entry of a lower bin is smaller.)  Crowded
 // bins -- many equal keys -- fall back to the radix passes.  Returns the k-th key.
-__device__ __attribute__((noinline)) Cand select_k(int count, int k)
+__device__ __attribute__((noinline)) Cand select_k(int count, int k, float key_limit)
 {
     WaveLds& L = g_L;
     const int lane = lane_id();
     // every pass reads UNR x 64 keys before using them, so the LDS latency is paid once per 512 entries
     constexpr int UNR = 8;
-    float mx = 0.f;
-    for (int base = 0; base < count; base += UNR * WAVE) {
-        float kv[UNR];
+    float mx = key_limit;          // > 0: no key exceeds it
+    if (!(mx > 0.f)) {
+        mx = 0.f;
+        for (int base = 0; base < count; base += UNR * WAVE) {
+            float kv[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; u++) { int j = base + u * WAVE + lane; kv[u] = j < count ? L.key[j] : 0.f; }
+            for (int u = 0; u < UNR; u++) { int j = base + u * WAVE + lane; kv[u] = j < count ? L.key[j] : 0.f; }
 #pragma unroll
-        for (int u = 0; u < UNR; u++) mx = fmaxf(mx, kv[u]);
+            for (int u = 0; u < UNR; u++) mx = fmaxf(mx, kv[u]);
+        }
+        for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     }
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
     const float scale = mx > 0.f ? 255.5f / mx : 0.f;
     for (int b = lane; b < 256; b += WAVE) L.hist[b] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -255,7 +260,7 @@ __device__ __attribute__((noinline)) Cand select_k(int count, int k)
         }
         __builtin_amdgcn_wave_barrier();
     }
-    return Cand{out, __uint_as_float(T)};
+    return Cand{out, __uint_as_float(T), 1};
 }
 
 __device__ __forceinline__ void append(int& count, bool take, float d2, uint32_t id)
@@ -280,7 +285,7 @@ __device__ __forceinline__ void make_room(Cand& c, int k, int need, Prof pf)
     if (c.count > CAP - need || c.count > early) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long t = pf.now();
-        c = select_k(c.count, k);
+        c = select_k(c.count, k, c.tight ? c.bound : 0.f);
         pf.add(P_SELECT, pf.now() - t); pf.add(P_N_SELECT, 1);
     }
 }
@@ -400,10 +405,10 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
 {
     WaveLds& L = g_L;
     const int lane = lane_id();
-    if (pm.n <= 0) return Cand{0, r2};
-    Cand c{0, r2};               // candidates need d2 < bound (Kdtree.cpp:77,82: strict)
+    if (pm.n <= 0) return Cand{0, r2, 0};
+    Cand c{0, r2, 0};            // candidates need d2 < bound (Kdtree.cpp:77,82: strict)
     const bool hinted = hint > 0.f && hint < r2;
-    if (hinted) c.bound = hint;
+    if (hinted) { c.bound = hint; c.tight = 1; }
 
     // ---- 1. near side down to a range of <= 2k photons, far sides onto the frontier
     int nf = 0;
@@ -442,7 +447,7 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
     pf.add(P_SCAN0, t0 - t1);
     if (c.count > k) {
         __builtin_amdgcn_wave_barrier();
-        c = select_k(c.count, k);
+        c = select_k(c.count, k, c.tight ? c.bound : 0.f);
         t1 = pf.now();
         pf.add(P_SELECT, t1 - t0); pf.add(P_N_SELECT, 1);
     }
@@ -538,7 +543,7 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
     if (c.count > k) {
         __builtin_amdgcn_wave_barrier();
         t0 = pf.now();
-        c = select_k(c.count, k);
+        c = select_k(c.count, k, c.tight ? c.bound : 0.f);
         pf.add(P_SELECT, pf.now() - t0); pf.add(P_N_SELECT, 1);
     }
     return c;
@@ -636,7 +641,9 @@ __device__ void estimate_raw(const PhotonMapView& pm, int count, const double* n
             if (valid[u]) {
                 float distanceSqr = dsq[u];
                 // gaussian filter, main.cpp:279 (float result of a double expression)
-                float weight = (float)(0.918 * (1 - (1 - exp(((-1.953 * (distanceSqr)) * inv_2max) * ln_base)) * inv_denom));
+                // the exponential itself in single precision: the weight is a float in the reference and enters a
+                // sum that is compared at 8-bit resolution
+                float weight = (float)(0.918 * (1 - (1 - (double)__expf((float)(((-1.953 * (distanceSqr)) * inv_2max) * ln_base))) * inv_denom));
                 float cosine = (float)(nrm[0] * (-(double)a[u][3]) + nrm[1] * (-(double)a[u][4]) + nrm[2] * (-(double)a[u][5]));   // main.cpp:281-283
                 if (cosine < 0) cosine = -cosine;
                 double sc = (double)(cosine * weight);
