@@ -273,6 +273,28 @@ void build_photon_map(const double* photons9, int64_t n, FlatPhotonMap& out, int
         out.pos[(size_t)i * 4 + 3] = (float)out.axis[i];
         for (int c = 0; c < 6; c++) out.aux[(size_t)i * 6 + c] = (float)p[3 + c];
     }
+    // bounding boxes of the leaves, found by the split rule the device walk uses
+    out.leaf_box.assign((size_t)(n / 32 + 1) * 6, 0.f);
+    std::vector<std::pair<int64_t, int64_t>> todo;
+    if (n > 0) todo.push_back({0, n});
+    while (!todo.empty()) {
+        auto [lo, hi] = todo.back();
+        todo.pop_back();
+        if (hi - lo > FlatPhotonMap::LEAF) {
+            int64_t mid = lo + (hi - lo) / 2;
+            todo.push_back({lo, mid});
+            todo.push_back({mid + 1, hi});
+            continue;
+        }
+        float* b = &out.leaf_box[(size_t)(lo / 32) * 6];
+        for (int c = 0; c < 3; c++) b[c] = b[3 + c] = out.pos[(size_t)lo * 4 + c];
+        for (int64_t i = lo + 1; i < hi; i++)
+            for (int c = 0; c < 3; c++) {
+                float v = out.pos[(size_t)i * 4 + c];
+                b[c] = std::min(b[c], v);
+                b[3 + c] = std::max(b[3 + c], v);
+            }
+    }
 }
 
 }  // namespace rth

@@ -39,6 +39,8 @@ struct FlatPhotonMap {
     std::vector<float> aux;        // 6 per photon: power rgb, dir xyz
     std::vector<uint8_t> axis;     // split axis of the node whose pivot this photon is
     std::vector<int32_t> order;    // tree position -> index in the caller's array
+    std::vector<float> leaf_box;   // 6 per slot (lo xyz, hi xyz of the float positions): slot = first photon of the leaf / 32
+                                   // (a leaf holds 33..64 photons unless it is the whole map, so the slots are distinct)
     int64_t n = 0;
 };
 

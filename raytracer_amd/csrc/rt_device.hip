@@ -91,7 +91,7 @@ struct rt_context {
     bool has_scene = false;
     DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
     // photon maps in HBM (0 surface, 1 volume)
-    DevBuf ph_pos[2], ph_aux[2], ph_axis[2], ph_order[2];
+    DevBuf ph_pos[2], ph_aux[2], ph_axis[2], ph_order[2], ph_box[2];
     rtg::PhotonMapView pm[2] = {};
     // render queues
     DevBuf hits_a, hits_b, rays, gq, acc;
@@ -279,7 +279,7 @@ void rt_context_destroy(rt_context* ctx)
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
                       &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
-                      &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1]})
+                      &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1], &ctx->ph_box[0], &ctx->ph_box[1]})
         b->release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -714,10 +714,12 @@ int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photo
     if ((rc = upload(ctx->ph_pos[which], fm.pos, ctx->stream))) return rc;
     if ((rc = upload(ctx->ph_aux[which], fm.aux, ctx->stream))) return rc;
     if ((rc = upload(ctx->ph_order[which], fm.order, ctx->stream))) return rc;
+    if ((rc = upload(ctx->ph_box[which], fm.leaf_box, ctx->stream))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->pm[which].pos = (const float4*)ctx->ph_pos[which].p;
     ctx->pm[which].aux = (const float*)ctx->ph_aux[which].p;
     ctx->pm[which].order = (const int*)ctx->ph_order[which].p;
+    ctx->pm[which].leaf_box = (const float*)ctx->ph_box[which].p;
     ctx->pm[which].n = n;
     return RT_OK;
 }

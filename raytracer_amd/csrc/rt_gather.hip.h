@@ -39,6 +39,7 @@ struct PhotonMapView {
     const float4* pos;           // per photon, tree order: x, y, z, split axis of the node whose pivot it is (0/1/2 as a float)
     const float* aux;            // 6 per photon: power rgb, dir xyz
     const int* order;            // tree position -> index in the caller's photon array
+    const float* leaf_box;       // 6 per slot: bounding box of the leaf whose first photon is 32 * slot .. 32 * slot + 31
     long long n;
 };
 
@@ -466,8 +467,17 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
         float rd2 = 0.f;
         if (lane < take) { rlo = L.f_lo[base + lane]; rhi = L.f_hi[base + lane]; rd2 = L.f_d2[base + lane]; }
         const bool live = lane < take && rhi > rlo && !(rd2 > c.bound);
-        const bool is_leaf = live && rhi - rlo <= WAVE;
-        const bool is_inner = live && !is_leaf;
+        const bool small = live && rhi - rlo <= WAVE;
+        bool is_leaf = small;
+        if (is_leaf) {
+            // a leaf whose box lies outside the bound holds no candidate.  The box distance is formed like a
+            // photon's distance from per-axis offsets that are no larger in magnitude, so in float, too,
+            // it never exceeds the distance of any photon inside.
+            const float* b = pm.leaf_box + 6 * (size_t)(rlo >> 5);
+            float ex = fmaxf(fmaxf(b[0] - qx, qx - b[3]), 0.f), ey = fmaxf(fmaxf(b[1] - qy, qy - b[4]), 0.f), ez = fmaxf(fmaxf(b[2] - qz, qz - b[5]), 0.f);
+            if (!(ex * ex + ey * ey + ez * ez < c.bound)) is_leaf = false;
+        }
+        const bool is_inner = live && !small;
         int mid = 0, nlo = 0, nhi = 0, flo = 0, fhi = 0;
         float dd = 0.f, d2 = 3.0e38f;
         if (is_inner) {
