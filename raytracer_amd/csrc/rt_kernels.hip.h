@@ -192,8 +192,9 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                             for (int i = 0; i < 3; i++) { lo[i] = second ? pn.lo1[i] : pn.lo0[i]; hi[i] = second ? pn.hi1[i] : pn.hi0[i]; }
                             if (!(rtm::slab_finite<R>(lo, hi, o, inv, dist) < R(0))) { cur = second ? pn.c1 : pn.c0; found = true; break; }   // BVH.cpp:132
                         } else {
-                            R t0 = s_t0[sp * WAVE + lane];
-                            if (!(t0 > dist)) { cur = s_ref[sp * WAVE + lane]; found = true; break; }
+                            const R t0 = s_t0[sp * WAVE + lane];
+                            const uint32_t ref = s_ref[sp * WAVE + lane];     // read with t0, not after the comparison
+                            if (!(t0 > dist)) { cur = ref; found = true; break; }
                         }
                     }
                     if (!found) break;
