@@ -144,7 +144,7 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
     return RT_OK;
 }
 
-// Launch geometry of the persistent traversal kernels.  LDS per block = node image (if staged) +
+// Launch geometry of the traversal kernels.  LDS per block = node image (if staged) +
 // per-wave stacks; the block size is chosen to keep the most waves resident per CU.
 struct TraceGeom { int threads, blocks; size_t lds; int mode; };   // mode: rtk::TRAV_*
 

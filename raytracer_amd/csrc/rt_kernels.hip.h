@@ -1,8 +1,9 @@
 // HIP kernels of the closest-hit path (gfx950, wave64).  Included by rt_device.hip only.
 //
 // K2  closest-hit traversal = BVH::Shoot (BVH.cpp:108-179) + the primitive tests, one ray per lane,
-//     persistent waves pulling 64-ray chunks / 8x8 pixel tiles from an atomic counter, per-lane
-//     traversal stack in LDS laid out [depth][lane] (bank = lane, conflict free).
+//     one 64-ray chunk / 8x8 pixel tile per wave (the hardware dispatcher places the blocks; there
+//     is no shared work counter), per-lane traversal stack in LDS laid out [depth][lane] (bank =
+//     lane, conflict free).
 // K1  primary-ray generation (main.cpp:753-790) is fused into the primary-ray kernel.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -248,35 +249,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
     return hit;
 }
 
-__device__ __forceinline__ unsigned long long wave_fetch(unsigned long long* counter, unsigned long long amount, int lane)
-{
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(counter, amount);
-    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)base);
-    unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // LDS layout of a block: [node image (node_bytes, may be 0)] [refs: waves x cap x 64 x 4 B] [t0: waves x cap x 64 x sizeof(R)]
-// Guided self-scheduling over [0, total): one returning atomic on a single word serves only ~90
-// requests per microsecond chip-wide, so waves take several units per request -- large batches
-// while plenty of work is left, single units near the end (load balance of the tail).
-struct WorkBatch {
-    unsigned long long begin = 0, end = 0;
-};
-__device__ __forceinline__ bool next_batch(WorkBatch& b, unsigned long long* counter, unsigned long long total, unsigned n_waves, int lane)
-{
-    // size from what was left when this wave last looked (first call: begin = end = 0 -> total / (4 waves))
-    unsigned long long left = total > b.end ? total - b.end : 0;
-    unsigned long long want = left / (4ull * n_waves);
-    want = want < 1 ? 1 : (want > 32 ? 32 : want);
-    unsigned long long base = wave_fetch(counter, want, lane);
-    if (base >= total) return false;
-    b.begin = base;
-    b.end = base + want < total ? base + want : total;
-    return true;
-}
-
 template <class R>
 __device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, size_t node_bytes = 0)
 {
@@ -295,7 +268,7 @@ __device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, siz
 // real_size = 0 for TRAV_RETEST (no entry distances)
 inline size_t stack_lds_bytes(int cap, size_t real_size, int waves = WAVES_PER_BLOCK) { return (size_t)waves * cap * WAVE * (sizeof(uint32_t) + real_size); }
 
-// counters[0] = work counter, counters[1] = stack-overflow flag, counters[2] = shadow rays traced
+// next: unused (kept for layout); overflow: stack-overflow flag; shadow: shadow rays traced; inner / prims: work of the counting build
 struct TraceCounters { unsigned long long next, overflow, shadow, inner, prims, pad[3]; };
 
 // Batch form of BVH::Shoot: rays in SoA doubles (x[n], y[n], z[n]).
