@@ -114,15 +114,6 @@ const rtf::SceneView<R>& view(const rt_context* ctx);
 template <> const rtf::SceneView<double>& view<double>(const rt_context* ctx) { return ctx->v64; }
 template <> const rtf::SceneView<float>& view<float>(const rt_context* ctx) { return ctx->v32; }
 
-int grid_blocks(const rt_context* ctx, size_t lds_bytes)
-{
-    // persistent grid: as many 256-thread blocks as stay resident (LDS- and wave-limited), capped at 8 per CU
-    int per_cu = 8;
-    if (lds_bytes > 0) per_cu = std::min<int>(per_cu, (int)((160 * 1024) / lds_bytes));
-    if (per_cu < 1) per_cu = 1;
-    return ctx->num_cus * per_cu;
-}
-
 int read_counters(rt_context* ctx, rtk::TraceCounters* out)
 {
     HIP_TRY(hipMemcpyAsync(out, ctx->counters.p, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
