@@ -291,3 +291,46 @@ def test_gpu_emission_statistics(gpu_ctx, tag, rgbs, ior):
         # photons lie on surfaces the host's photons lie on: every GPU photon has a host photon nearby
     d = np.linalg.norm(dev[0][:2000, None, :3] - host[0][None, ::7, :3], axis=-1).min(1)
     assert np.median(d) < 0.05
+
+
+def test_full_frame_glass_against_oracle(gpu_ctx):
+    """Configuration C3 at its full 3840x2160: glass teapot with smooth normals, recursion depth 4, no
+    photon map, the whole frame against the CPU oracle (recursion on the newly hit object)."""
+    import os
+    rgbs, ior, off = (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0)
+    s = build_scene(rt.Scene(), "teapot_normal.obj", rgbs, ior, off)
+    orc = build_scene(Oracle(), "teapot_normal.obj", rgbs, ior, off)
+    gpu_ctx.upload(s)
+    w, h = 3840, 2160
+    p = rt.default_params(width=w, height=h, use_photon_map=0)
+    rgb, bgr, st = gpu_ctx.render(rt.look_at(CAM[:3], CAM[3:]), p)
+    orc.params.head_quirk = 0
+    orc.params.use_photon_map = 0
+    ref, nrays = orc.render(w, h, CAM, threads=min(16, os.cpu_count() or 1))
+    within, rmse = assert_image_close(rgb, ref, what="C3 3840x2160")
+    assert within == 1.0
+    assert st.primary_rays == w * h and st.secondary_rays > 100000
+
+
+def test_large_frame_photon_map_against_oracle(gpu_ctx):
+    """Configuration C4 scaled to what the CPU oracle finishes in seconds: water surface + Cornell box,
+    200 000 emitted photons, k = 500, 960x540 -- every diffuse pixel is a gather."""
+    import os
+    rgbs, ior = (0.26, 0.84, 1.0, 1.8), 1.33
+    s = build_scene(rt.Scene(), "water.obj", rgbs, ior)
+    orc = build_scene(Oracle(), "water.obj", rgbs, ior)
+    s.emit_photons(200000, seed=12345)
+    ph = s.photons_get()
+    orc.photons_set(np.c_[ph, np.zeros(len(ph))])
+    orc.build_kdtree()
+    gpu_ctx.upload(s)
+    gpu_ctx.photons_upload(ph)
+    w, h = 960, 540
+    p = rt.default_params(width=w, height=h, photon_num=200000, photon_use=500)
+    rgb, bgr, st = gpu_ctx.render(rt.look_at(CAM[:3], CAM[3:]), p)
+    orc.params.head_quirk = 0
+    orc.params.photon_num = 200000
+    orc.params.photon_use = 500
+    ref, _ = orc.render(w, h, CAM, threads=min(16, os.cpu_count() or 1))
+    assert_image_close(rgb, ref, what="C4 960x540")
+    assert st.gather_queries > 100000
