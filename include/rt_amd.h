@@ -163,6 +163,14 @@ void rt_scene_photons_clear(rt_scene* s);
 /* ---- device: scene + traversal ----------------------------------------------------------- */
 /* copy the flattened scene (64 B-aligned node / primitive / material arrays, f64 and f32 forms) to HBM */
 int rt_scene_upload(rt_context* ctx, const rt_scene* s);
+/* The same upload with the tree built on the GPU instead of taking the host tree of
+ * rt_scene_build_bvh (which need not have been called): a linear BVH over Morton-sorted
+ * primitives, milliseconds instead of seconds for millions of triangles.  NOT the reference's
+ * tree (BVH.cpp:57-96): closest hits agree with it except where the reference's own box culling
+ * decides (hits within rounding of a box face) and on exact ties, so this form is checked against
+ * exhaustive intersection, not against the reference's goldens.  build_ms (optional): device time
+ * of the build. */
+int rt_scene_upload_lbvh(rt_context* ctx, const rt_scene* s, double* build_ms);
 
 /* BVH::Shoot(ray, dist) for a batch, BVH.cpp:108.  org/dir: n x 3 doubles; dist: in = max range
  * (the reference's in/out `distance`), out = hit distance (unchanged on a miss); ids: object id or -1.

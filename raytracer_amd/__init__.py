@@ -166,6 +166,12 @@ class Context:
     def upload(self, scene):
         _chk(lib.rt_scene_upload(self.h, scene.h), "rt_scene_upload")
 
+    def upload_lbvh(self, scene):
+        """Upload with the tree built on the GPU (linear BVH, not the reference's tree); returns the build's device ms."""
+        ms = ctypes.c_double(0)
+        _chk(lib.rt_scene_upload_lbvh(self.h, scene.h, ctypes.byref(ms)), "rt_scene_upload_lbvh")
+        return ms.value
+
     def trace_closest(self, org, d, max_dist=1e9, precision=RT_F64):
         org = _f64(org); d = _f64(d)
         n = org.shape[0]

@@ -270,6 +270,8 @@ inline Box unite(const Box& a, const Box& b)   // BBox::Union, BVH.cpp:31-40
 // BBox::Size, BVH.h:33-38 -- evaluation order kept (it decides which split wins on near-ties)
 inline double extent_sum(const Box& b) { return b.hi[0] - b.lo[0] + b.hi[1] - b.lo[1] + b.hi[2] - b.lo[2]; }
 
+}  // namespace
+
 rtf::Prim<double> make_prim(const rtf::ObjShade& o, uint32_t id)
 {
     rtf::Prim<double> p{};
@@ -283,6 +285,8 @@ rtf::Prim<double> make_prim(const rtf::ObjShade& o, uint32_t id)
     }
     return p;
 }
+
+namespace {
 
 struct Builder {
     const std::vector<Object>& objs;

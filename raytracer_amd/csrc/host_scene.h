@@ -50,6 +50,8 @@ struct Scene {
 };
 
 Box object_box(const rtf::ObjShade& o);
+// traversal record of an object: A, B - A, C - A (triangle) or centre, radius (sphere) or normal, distance (plane)
+rtf::Prim<double> make_prim(const rtf::ObjShade& o, uint32_t id);
 
 // float copies of the flattened arrays
 std::vector<rtf::Node<float>> to_f32(const std::vector<rtf::Node<double>>& n);

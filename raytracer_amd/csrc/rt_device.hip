@@ -17,6 +17,7 @@
 #include "rt_kernels.hip.h"
 #include "rt_math.h"
 #include "rt_emit.hip.h"
+#include "rt_lbvh.hip.h"
 #include "rt_render.hip.h"
 
 namespace {
@@ -532,6 +533,29 @@ void rt_scene_photons_clear(rt_scene* s)
 }
 
 // ---------------------------------------------------------------- device scene
+}  // extern "C"
+namespace {
+// per-object shading records and the texel pool (synchronises: the host copies die at return)
+int upload_shading(rt_context* ctx, const rth::Scene& s)
+{
+    int rc;
+    std::vector<rtf::ObjShade> sh(s.objects.size());
+    for (size_t i = 0; i < sh.size(); i++) sh[i] = s.objects[i].sh;
+    if ((rc = upload(ctx->objs, sh, ctx->stream))) return rc;
+    std::vector<rtf::TexDesc> td;
+    std::vector<double> pool;
+    for (const auto& t : s.textures) {
+        td.push_back({t.x_res, t.y_res, (int64_t)pool.size()});
+        pool.insert(pool.end(), t.rgb.begin(), t.rgb.end());
+    }
+    if ((rc = upload(ctx->texdesc, td, ctx->stream))) return rc;
+    if ((rc = upload(ctx->texels, pool, ctx->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+}  // namespace
+extern "C" {
+
 int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
 {
     if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
@@ -549,17 +573,7 @@ int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
     if ((rc = upload(ctx->nodes32, n32, ctx->stream))) return rc;
     if ((rc = upload(ctx->prims32, p32, ctx->stream))) return rc;
     if ((rc = upload(ctx->planes32, pl32, ctx->stream))) return rc;
-    std::vector<rtf::ObjShade> sh(s.objects.size());
-    for (size_t i = 0; i < sh.size(); i++) sh[i] = s.objects[i].sh;
-    if ((rc = upload(ctx->objs, sh, ctx->stream))) return rc;
-    std::vector<rtf::TexDesc> td;
-    std::vector<double> pool;
-    for (const auto& t : s.textures) {
-        td.push_back({t.x_res, t.y_res, (int64_t)pool.size()});
-        pool.insert(pool.end(), t.rgb.begin(), t.rgb.end());
-    }
-    if ((rc = upload(ctx->texdesc, td, ctx->stream))) return rc;
-    if ((rc = upload(ctx->texels, pool, ctx->stream))) return rc;
+    if ((rc = upload_shading(ctx, s))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));   // the host vectors above die at return
 
     ctx->v64.nodes = (const rtf::Node<double>*)ctx->nodes64.p;
@@ -579,6 +593,130 @@ int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
     ctx->v64.tri_only = ctx->v32.tri_only = tri_only ? 1 : 0;
     ctx->depth = b.depth;
     ctx->n_nodes = (int)b.nodes.size();
+    ctx->n_objects = (int)s.objects.size();
+    ctx->has_scene = true;
+    return RT_OK;
+}
+
+int rt_scene_upload_lbvh(rt_context* ctx, const rt_scene* scene, double* build_ms)
+{
+    if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
+    const rth::Scene& s = scene->s;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    std::vector<rtf::Prim<double>> prims, planes;
+    bool tri_only = true;
+    for (size_t i = 0; i < s.objects.size(); i++) {
+        const rtf::ObjShade& o = s.objects[i].sh;
+        if (o.kind == rtf::PRIM_PLANE) { planes.push_back(rth::make_prim(o, (uint32_t)i)); continue; }
+        prims.push_back(rth::make_prim(o, (uint32_t)i));
+        tri_only = tri_only && o.kind == rtf::PRIM_TRI;
+    }
+    const long long n = (long long)prims.size();
+    if (n >= (1ll << rtf::LEAF_COUNT_SHIFT)) return fail(RT_ERR_LIMIT, "%lld primitives exceed the leaf reference range", n);
+    auto pl32 = rth::to_f32(planes);
+    if ((rc = upload(ctx->planes64, planes, ctx->stream))) return rc;
+    if ((rc = upload(ctx->planes32, pl32, ctx->stream))) return rc;
+    if ((rc = upload_shading(ctx, s))) return rc;
+
+    // working set of the build, carved out of the context's scratch buffers
+    const long long ni = n > 1 ? n - 1 : 0;
+    DevBuf &in = ctx->hits_a, &work = ctx->hits_b, &tmp = ctx->rays;
+    if ((rc = upload(in, prims, ctx->stream))) return rc;
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t at = off; off += align(bytes); return at; };
+    const size_t o_pbox = carve(n * sizeof(rtl::Box6)), o_lbox = carve(n * sizeof(rtl::Box6)), o_nbox = carve(ni * sizeof(rtl::Box6));
+    const size_t o_key = carve(n * 8), o_key2 = carve(n * 8), o_val = carve(n * 4), o_val2 = carve(n * 4);
+    const size_t o_left = carve(ni * 4), o_right = carve(ni * 4), o_first = carve(ni * 4), o_last = carve(ni * 4), o_pin = carve(ni * 4), o_plf = carve(n * 4);
+    const size_t o_arr = carve(ni * 4), o_keep = carve(ni * 4), o_new = carve(ni * 4), o_cb = carve(64), o_depth = carve(64);
+    if ((rc = work.reserve(off + 256))) return rc;
+    char* w = (char*)work.p;
+    auto* pbox = (rtl::Box6*)(w + o_pbox); auto* lbox = (rtl::Box6*)(w + o_lbox); auto* nbox = (rtl::Box6*)(w + o_nbox);
+    auto* key = (unsigned long long*)(w + o_key); auto* key2 = (unsigned long long*)(w + o_key2);
+    auto* val = (uint32_t*)(w + o_val); auto* val2 = (uint32_t*)(w + o_val2);
+    auto* left = (uint32_t*)(w + o_left); auto* right = (uint32_t*)(w + o_right); auto* first = (uint32_t*)(w + o_first); auto* last = (uint32_t*)(w + o_last);
+    auto* pin = (uint32_t*)(w + o_pin); auto* plf = (uint32_t*)(w + o_plf); auto* arrived = (unsigned*)(w + o_arr);
+    auto* keep = (uint32_t*)(w + o_keep); auto* newidx = (uint32_t*)(w + o_new);
+    auto* cb = (unsigned long long*)(w + o_cb); int* d_depth = (int*)(w + o_depth);
+
+    if ((rc = ctx->prims64.reserve(std::max<size_t>(64, n * sizeof(rtf::Prim<double>))))) return rc;
+    if ((rc = ctx->prims32.reserve(std::max<size_t>(64, n * sizeof(rtf::Prim<float>))))) return rc;
+    uint32_t root_ref = rtf::NO_NODE;
+    rtl::Box6 root_box{};
+    int depth = 0;
+    size_t n_nodes = 0;
+    float ms = 0;
+    if (n > 0) {
+        const int T = 256;
+        auto grid = [&](long long m) { return dim3((unsigned)((m + T - 1) / T)); };
+        size_t sort_bytes = 0, scan_bytes = 0;
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, key, key2, val, val2, (int)n, 0, 63, ctx->stream));
+        if (ni) HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, newidx, (int)ni, ctx->stream));
+        if ((rc = tmp.reserve(std::max(sort_bytes, scan_bytes) + 256))) return rc;
+        unsigned long long cb0[8] = {~0ull, ~0ull, ~0ull, 0, 0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(cb, cb0, sizeof cb0, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemsetAsync(d_depth, 0, 4, ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        hipLaunchKernelGGL(rtl::bounds_kernel, grid(n), dim3(T), 0, ctx->stream, (const rtf::Prim<double>*)in.p, n, pbox, cb);
+        hipLaunchKernelGGL(rtl::morton_kernel, grid(n), dim3(T), 0, ctx->stream, pbox, n, cb, key, val);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, sort_bytes, key, key2, val, val2, (int)n, 0, 63, ctx->stream));
+        if (ni) {
+            HIP_TRY(hipMemsetAsync(arrived, 0, ni * 4, ctx->stream));
+            hipLaunchKernelGGL(rtl::radix_tree_kernel, grid(ni), dim3(T), 0, ctx->stream, rtl::Radix{key2, n}, left, right, first, last, pin, plf);
+        }
+        hipLaunchKernelGGL(rtl::refit_kernel, grid(n), dim3(T), 0, ctx->stream, n, val2, pbox, lbox, nbox, left, right, pin, plf, arrived);
+        if (ni) {
+            hipLaunchKernelGGL(rtl::keep_kernel, grid(ni), dim3(T), 0, ctx->stream, ni, first, last, keep);
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, scan_bytes, keep, newidx, (int)ni, ctx->stream));
+        }
+        hipLaunchKernelGGL(rtl::emit_prims_kernel, grid(n), dim3(T), 0, ctx->stream, n, val2, (const rtf::Prim<double>*)in.p, (rtf::Prim<double>*)ctx->prims64.p,
+                           (rtf::Prim<float>*)ctx->prims32.p);
+        HIP_TRY(hipGetLastError());
+        uint32_t last_keep = 0, last_new = 0;
+        if (ni) {
+            HIP_TRY(hipMemcpyAsync(&last_keep, keep + ni - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(&last_new, newidx + ni - 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_TRY(hipMemcpyAsync(&root_box, ni ? nbox : lbox, sizeof root_box, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        n_nodes = (size_t)last_keep + last_new;
+        if ((rc = ctx->nodes64.reserve(std::max<size_t>(64, n_nodes * sizeof(rtf::Node<double>))))) return rc;
+        if ((rc = ctx->nodes32.reserve(std::max<size_t>(64, n_nodes * sizeof(rtf::Node<float>))))) return rc;
+        if (n_nodes) {
+            rtl::EmitArgs ea{left, right, first, last, keep, newidx, pin, lbox, nbox};
+            hipLaunchKernelGGL(rtl::emit_nodes_kernel, grid(ni), dim3(T), 0, ctx->stream, ni, ea, (rtf::Node<double>*)ctx->nodes64.p,
+                               (rtf::Node<float>*)ctx->nodes32.p, d_depth);
+            HIP_TRY(hipGetLastError());
+            root_ref = 0;      // the radix tree's root is inner node 0, first in the renumbering
+        } else {
+            root_ref = rtf::make_leaf(0, (uint32_t)n);
+        }
+        HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(hipMemcpyAsync(&depth, d_depth, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    } else {
+        if ((rc = ctx->nodes64.reserve(64))) return rc;
+        if ((rc = ctx->nodes32.reserve(64))) return rc;
+    }
+    if (build_ms) *build_ms = ms;
+
+    ctx->v64.nodes = (const rtf::Node<double>*)ctx->nodes64.p;
+    ctx->v64.prims = (const rtf::Prim<double>*)ctx->prims64.p;
+    ctx->v64.planes = (const rtf::Prim<double>*)ctx->planes64.p;
+    ctx->v32.nodes = (const rtf::Node<float>*)ctx->nodes32.p;
+    ctx->v32.prims = (const rtf::Prim<float>*)ctx->prims32.p;
+    ctx->v32.planes = (const rtf::Prim<float>*)ctx->planes32.p;
+    for (int i = 0; i < 3; i++) {
+        ctx->v64.root_lo[i] = root_box.lo[i]; ctx->v64.root_hi[i] = root_box.hi[i];
+        ctx->v32.root_lo[i] = (float)root_box.lo[i]; ctx->v32.root_hi[i] = (float)root_box.hi[i];
+    }
+    ctx->v64.root_ref = ctx->v32.root_ref = root_ref;
+    ctx->v64.n_planes = ctx->v32.n_planes = (int32_t)planes.size();
+    ctx->v64.tri_only = ctx->v32.tri_only = tri_only ? 1 : 0;
+    ctx->depth = depth;
+    ctx->n_nodes = (int)n_nodes;
     ctx->n_objects = (int)s.objects.size();
     ctx->has_scene = true;
     return RT_OK;

@@ -1,0 +1,105 @@
+"""The opt-in device-built tree (rt_scene_upload_lbvh: linear BVH over Morton-sorted primitives).
+It is NOT the reference's tree, so it is checked against exhaustive intersection (the property the
+reference's own BVHSelfTest checks, BVH.cpp:181-260) and against the traversal of the reference tree,
+not against the goldens."""
+import os
+
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from conftest import CAM, DATA, build_scene
+from oracle.bindings import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(n, seed, lo=-1.5, hi=1.5):
+    rng = np.random.default_rng(seed)
+    org = rng.uniform(lo, hi, (n, 3))
+    d = rng.normal(size=(n, 3))
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    return org, d
+
+
+@pytest.mark.parametrize("mesh", ["teapot_normal.obj", "water.obj"])
+def test_lbvh_equals_exhaustive_intersection(gpu_ctx, mesh):
+    s = build_scene(rt.Scene(), mesh)
+    orc = build_scene(Oracle(), mesh)
+    ms = gpu_ctx.upload_lbvh(s)
+    assert ms > 0
+    org, d = _rays(40000, 3)
+    ids, t = gpu_ctx.trace_closest(org, d)
+    bid, bt = orc.brute_force(org, d)
+    assert np.array_equal(t, bt)                      # the closest distance is the same number
+    assert (ids == bid).mean() > 0.9999               # ids differ only on exact ties
+    assert np.array_equal(ids >= 0, bid >= 0)
+    # the same frame through the reference tree: same image
+    p = rt.default_params(width=640, height=360)
+    ids_l, t_l, _, _ = gpu_ctx.trace_primary(rt.look_at(CAM[:3], CAM[3:]), p)
+    gpu_ctx.upload(s)
+    ids_r, t_r, _, _ = gpu_ctx.trace_primary(rt.look_at(CAM[:3], CAM[3:]), p)
+    # ids may differ where two triangles give the very same t (a ray through a shared edge, e.g. a wall's
+    # diagonal): the distance image is identical
+    assert np.array_equal(np.where(ids_l >= 0, t_l, 1e9), np.where(ids_r >= 0, t_r, 1e9))
+    assert (ids_l != ids_r).mean() < 1e-3
+
+
+def test_lbvh_mixed_primitives_small_and_empty_scenes(gpu_ctx):
+    def fill(api, n_tri, n_sph):
+        r2 = np.random.default_rng(21)
+        for i in range(n_tri):
+            A, C, B = r2.uniform(-1, 1, (3, 3))
+            api.add_triangle(A, C, B, (0.3, 0.6, 0.9, 0.0), 1.5)
+        for i in range(n_sph):
+            api.add_sphere(r2.uniform(-0.8, 0.8, 3), float(r2.uniform(0.05, 0.4)), (1, 1, 1, 0.9), 1.5)
+        api.add_plane((0.0, 1.0, 0.0), -1.0, (0.5, 0.5, 0.5, 0))
+        api.build_bvh()
+        return api
+    org, d = _rays(20000, 4)
+    for n_tri, n_sph in [(60, 0), (1, 0), (7, 0), (16, 0), (0, 0), (60, 30)]:
+        s, orc = fill(rt.Scene(), n_tri, n_sph), fill(Oracle(), n_tri, n_sph)
+        gpu_ctx.upload_lbvh(s)
+        ids, t = gpu_ctx.trace_closest(org, d)
+        sid, st_ = orc.shoot(org, d)      # the reference traversal (tree) + the plane side list
+        if n_sph == 0:
+            assert np.array_equal(t, st_), (n_tri, n_sph)
+            assert (ids == sid).mean() > 0.999, (n_tri, n_sph)
+        else:
+            # Sphere::findIntersection's second root (Sphere.h:83) is not a geometric intersection, so which
+            # spheres answer depends on which boxes a ray happens to enter: only near-agreement between trees
+            assert (t == st_).mean() > 0.97
+            assert ((ids >= 60) & (ids < 90)).any()
+
+
+def test_lbvh_large_scene_and_render_path(gpu_ctx):
+    """49 teapots: the device tree against the reference tree on a frame, in both precisions; then the
+    whole render path (bounce queue) on a glass teapot with either tree."""
+    s = rt.Scene()
+    for i in range(7):
+        for j in range(7):
+            s.load_obj(os.path.join(DATA, "teapot_normal.obj"), off=(0.0, i * 1.5, j * 1.5))
+    s.build_bvh()
+    cam = rt.look_at((9.0, 4.5, 4.5), (0.0, 4.5, 4.5))
+    out = {}
+    for tree in ("lbvh", "reference"):
+        ms = gpu_ctx.upload_lbvh(s) if tree == "lbvh" else gpu_ctx.upload(s)
+        for prec in (rt.RT_F64, rt.RT_F32):
+            out[tree, prec] = gpu_ctx.trace_primary(cam, rt.default_params(width=480, height=300, precision=prec))[:2]
+    for prec in (rt.RT_F64, rt.RT_F32):
+        il, tl = out["lbvh", prec]
+        ir, tr = out["reference", prec]
+        assert (il != ir).mean() < 1e-3, prec
+        if prec == rt.RT_F64:
+            assert np.array_equal(np.where(il >= 0, tl, 1e9), np.where(ir >= 0, tr, 1e9))
+        else:   # float boxes are rounded, not widened: a hit within float rounding of a box face may be culled by one tree only
+            assert (np.where(il >= 0, tl, 1e9) != np.where(ir >= 0, tr, 1e9)).mean() < 1e-3
+    g = build_scene(rt.Scene(), "teapot_normal.obj", (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
+    p = rt.default_params(width=320, height=180, use_photon_map=0)
+    gpu_ctx.upload(g)
+    ref, _, _ = gpu_ctx.render(rt.look_at(CAM[:3], CAM[3:]), p)
+    gpu_ctx.upload_lbvh(g)
+    got, _, st = gpu_ctx.render(rt.look_at(CAM[:3], CAM[3:]), p)
+    a, b = np.floor(np.clip(got, 0, 1) * 255), np.floor(np.clip(ref, 0, 1) * 255)
+    assert (np.abs(a - b).max(-1) <= 1).mean() > 0.999
+    assert st.secondary_rays > 0

@@ -94,6 +94,18 @@ def main():
                 rays = st.primary_rays + st.shadow_rays
                 hits = int((buf[0] >= 0).sum().item())
                 print(f"C5 {name} {w}x{h} shadow={shadow}: {rays} rays ({hits} primary hits), kernel {st.trace_kernel_ms:.2f} ms -> {rays / st.trace_kernel_ms / 1e3:.0f} Mrays/s", flush=True)
+        ref_ids = buf[0].clone()
+        t0 = time.perf_counter()
+        ms = ctx.upload_lbvh(s)
+        t1 = time.perf_counter()
+        print(f"C5 device-built tree (linear BVH): {ms:.1f} ms of kernels, {t1 - t0:.2f} s wall with the upload", flush=True)
+        for prec, name in ((rt.RT_F64, "f64"), (rt.RT_F32, "f32")):
+            p = rt.default_params(width=w, height=h, precision=prec, shadow_rays=0)
+            for _ in range(2):
+                st = ctx.trace_primary_dev(cam, p, (0, h), buf[0].data_ptr(), None, buf[1].data_ptr())
+            diff = float((buf[0] != ref_ids).float().mean().item()) if prec == rt.RT_F32 else float("nan")
+            print(f"C5 {name} on the device-built tree: kernel {st.trace_kernel_ms:.2f} ms -> {st.primary_rays / st.trace_kernel_ms / 1e3:.0f} Mrays/s"
+                  + (f" (ids differing from the reference tree's f32 frame: {diff:.2e})" if prec == rt.RT_F32 else ""), flush=True)
 
 
 if __name__ == "__main__":
