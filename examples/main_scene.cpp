@@ -4,6 +4,7 @@
 // (photon emission, per-pixel ray trace) handed to Renderer, which runs the pixel loop on the GPU.
 //
 //   main_scene <mesh.obj> <out.bmp> [width height photons seed special ior yoff]
+//   RT_DEVICE_TREE=1 builds the BVH on the GPU instead of the reference's tree on the host.
 #include "../raytracer_amd/scene/System.h"
 
 #include "../raytracer_amd/scene/BVH.h"
@@ -64,7 +65,8 @@ int main(int argc, char* argv[])
     if (!objReader->ReadContent(&scene_objects)) fprintf(stderr, "warning: %s not loaded\n", argv[1]);
     makeCornellBox(scene_objects, Vect(1, 1, 1), Vect(-1, -1, -1));
 
-    bvh = new BVH(scene_objects);
+    const char* device_tree = getenv("RT_DEVICE_TREE");
+    bvh = new BVH(scene_objects, device_tree && atoi(device_tree) != 0);
 
     Renderer renderer(bvh);
     renderer.emitPhotons(photon_count, scene_light.getLightPosition(), seed, photons, volumePhotons);

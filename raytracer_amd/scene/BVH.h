@@ -3,6 +3,11 @@
 // leaf order and boxes) and flattens it; the flattened tree is copied to HBM.  Shoot() is the
 // single-ray form of the batch entry point rt_trace_closest -- correct but latency bound; the
 // pixel loop should go through Renderer, which keeps rays on the device.
+//
+// BVH(objects, true) builds a linear BVH on the GPU instead (milliseconds for millions of
+// triangles): the same closest hits except on exact ties between primitives, where the reference's
+// visiting order decides; the reference's host tree is then built only if something needs it
+// (host_tree(), used by the serial photon emission).
 #pragma once
 #include <vector>
 
@@ -14,15 +19,20 @@
 class BVH {
     std::vector<Object*> objects;   // borrowed, as in the reference (BVH.cpp:103)
     rt_scene* scene = nullptr;
+    bool host_built = false;
 
 public:
-    BVH(std::vector<Object*>& in_objects) : objects(in_objects)
+    BVH(std::vector<Object*>& in_objects, bool device_build = false) : objects(in_objects)
     {
         rt::check(rt_scene_create(&scene), "rt_scene_create");
         SceneSink sink;
         sink.scene = scene;
         for (Object* o : objects) rt::check(o->describe(sink), "Object::describe");
-        rt::check(rt_scene_build_bvh(scene), "rt_scene_build_bvh");
+        if (device_build) {
+            rt::check(rt_scene_upload_lbvh(rt::device(), scene, nullptr), "rt_scene_upload_lbvh");
+            return;
+        }
+        host_tree();
         rt::check(rt_scene_upload(rt::device(), scene), "rt_scene_upload");
     }
     ~BVH() { rt_scene_destroy(scene); }
@@ -47,5 +57,12 @@ public:
     }
 
     rt_scene* host_scene() const { return scene; }
+    // the host scene with the reference's tree built (BVH.cpp:98)
+    rt_scene* host_tree()
+    {
+        if (!host_built) rt::check(rt_scene_build_bvh(scene), "rt_scene_build_bvh");
+        host_built = true;
+        return scene;
+    }
     const std::vector<Object*>& scene_objects() const { return objects; }
 };

@@ -27,7 +27,7 @@ public:
     void emitPhotons(long long n_emit, Vect light_position, unsigned seed, std::vector<Photon*>& photons, std::vector<Photon*>& volumePhotons,
                      int bounce = 5, double accuracy = 0.000001, bool on_device = false)
     {
-        rt_scene* s = bvh->host_scene();
+        rt_scene* s = on_device ? bvh->host_scene() : bvh->host_tree();
         rt_scene_photons_clear(s);
         if (on_device)
             rt::check(rt_scene_emit_photons_gpu(rt::device(), s, n_emit, light_position.data(), seed, bounce, accuracy, nullptr), "rt_scene_emit_photons_gpu");

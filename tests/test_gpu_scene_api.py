@@ -14,13 +14,15 @@ from oracle.bindings import Oracle
 pytestmark = pytest.mark.gpu
 
 
-def test_main_style_scene_program(tmp_path):
+@pytest.mark.parametrize("device_tree", [False, True])
+def test_main_style_scene_program(tmp_path, device_tree):
     exe = os.path.join(ROOT, "examples", "main_scene")
     assert os.path.exists(exe), "examples/main_scene missing: run __graft_entry__.build()"
     out = str(tmp_path / "scene.bmp")
     w, h, nph, seed = 96, 72, 3000, 12345
     r = subprocess.run([exe, os.path.join(DATA, "teapot_normal.obj"), out, str(w), str(h), str(nph), str(seed), "1.8", "1.5", "-0.7"],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120,
+                       env=dict(os.environ, RT_DEVICE_TREE="1" if device_tree else "0"))
     assert r.returncode == 0, r.stdout
     assert "centre ray hits an object" in r.stdout
     raw = np.fromfile(out, np.uint8)
@@ -36,4 +38,7 @@ def test_main_style_scene_program(tmp_path):
     rgb, _ = orc.render(w, h, CAM, threads=8)
     ref = orc.quantize(rgb).reshape(h, w, 3).astype(np.int32)
     within = (np.abs(got - ref).max(axis=-1) <= 1).mean()
-    assert within >= 0.999, within
+    # The device-built tree has widened boxes; the reference's exact boxes reject some hits of refracted
+    # rays that start on a box face (a triangle's own vertices span its leaf's box), which an exhaustive
+    # search finds.  A few glass pixels therefore differ and the bar for that tree is 99 %.
+    assert within >= (0.99 if device_tree else 0.999), within
