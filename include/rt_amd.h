@@ -195,6 +195,22 @@ int rt_trace_primary(rt_context* ctx, const rt_camera* cam, const rt_render_para
  * host (same topology), flattens it and copies it to HBM.  photons: n x 9 doubles
  * (position, power rgb, direction; Photon.h:7-28).  which: 0 surface map, 1 volume map. */
 int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photons);
+/* The same with the kd-tree built on the GPU (Kdtree.cpp:11-52 level by level: widest axis of each
+ * range from its bounds, median by a sort of the whole array keyed by (range, coordinate)).  Same
+ * split rule on the float positions the gather reads; photons of equal coordinate may fall on
+ * either side of a pivot, which no k-NN result depends on. */
+int rt_photons_upload_dev_build(rt_context* ctx, int which, int64_t n, const double* photons);
+/* main.cpp:683-727 without leaving the GPU: emission as rt_scene_emit_photons_gpu (same random
+ * streams, so the same photons), the lists put in (photon number, bounce) order, both kd-trees built
+ * on the device.  The scene must have been uploaded.  counts (optional): photons in the surface and
+ * volume maps.  stats (optional): secondary_rays = Shoot calls, trace_kernel_ms = emission,
+ * kernel_ms = emission + ordering + tree builds. */
+int rt_emit_photon_maps_dev(rt_context* ctx, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy,
+                            int64_t counts[2], rt_stats* stats);
+/* photons in map `which` of the context; rt_photon_map_get copies the n x 9 doubles of a map built on
+ * the device (by the two calls above), in list order */
+int64_t rt_photon_map_size(const rt_context* ctx, int which);
+int rt_photon_map_get(rt_context* ctx, int which, double* photons);
 /* KDTree::findKNN(k, center), Kdtree.cpp:135, for a batch: counts[n], and (optional) the squared
  * distance of the farthest returned photon r2[n] (-1 when none). */
 int rt_knn_radius(rt_context* ctx, int which, int k, double max_dist, int64_t n, const double* centers, int32_t* counts, double* r2);

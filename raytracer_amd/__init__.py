@@ -210,6 +210,40 @@ def _ctx_photons_upload(self, photons, which=0):
     _chk(lib.rt_photons_upload(self.h, which, photons.shape[0], _dp(photons)), "rt_photons_upload")
 
 
+def _ctx_photons_upload_dev_build(self, photons, which=0):
+    """As photons_upload, the kd-tree built on the GPU."""
+    photons = _f64(photons)
+    assert photons.ndim == 2 and photons.shape[1] == 9
+    _chk(lib.rt_photons_upload_dev_build(self.h, which, photons.shape[0], _dp(photons)), "rt_photons_upload_dev_build")
+
+
+def _ctx_emit_photon_maps(self, n_emit, light_pos=(0.1, 0.2, 0.0), seed=12345, bounce=5, accuracy=1e-6):
+    """Emission + ordering + both kd-trees on the GPU; returns ((surface, volume) counts, Stats)."""
+    st = Stats()
+    counts = (_lib.c_i64 * 2)(0, 0)
+    _chk(lib.rt_emit_photon_maps_dev(self.h, n_emit, _dp(_f64(light_pos)), seed, bounce, accuracy, counts, ctypes.byref(st)),
+         "rt_emit_photon_maps_dev")
+    return (counts[0], counts[1]), st
+
+
+def _ctx_photon_map_get(self, which=0):
+    n = lib.rt_photon_map_size(self.h, which)
+    out = np.zeros((max(n, 0), 9))
+    _chk(lib.rt_photon_map_get(self.h, which, _dp(out)), "rt_photon_map_get")
+    return out
+
+
+def _ctx_knn_query(self, k, centers, max_dist=0.28, which=0):
+    """KDTree::findKNN for a batch: (idx [n, k] into the uploaded photon list, -1 padded, unordered; counts [n])."""
+    centers = _f64(centers)
+    n = centers.shape[0]
+    idx = np.full((n, k), -1, np.int32)
+    cnt = np.zeros(n, np.int32)
+    _chk(lib.rt_knn_query(self.h, which, k, max_dist, n, _dp(centers), idx.ctypes.data_as(_lib.P(_lib.c_i32)),
+                          cnt.ctypes.data_as(_lib.P(_lib.c_i32))), "rt_knn_query")
+    return idx, cnt
+
+
 def _ctx_knn_radius(self, k, centers, max_dist=0.28, which=0):
     centers = _f64(centers)
     n = centers.shape[0]
@@ -250,6 +284,10 @@ def _ctx_render_dev(self, cam, params, rows, d_rgb, d_bgr8, stats=True):
 
 
 Context.photons_upload = _ctx_photons_upload
+Context.photons_upload_dev_build = _ctx_photons_upload_dev_build
+Context.emit_photon_maps = _ctx_emit_photon_maps
+Context.photon_map_get = _ctx_photon_map_get
+Context.knn_query = _ctx_knn_query
 Context.knn_radius = _ctx_knn_radius
 Context.knn_estimate = _ctx_knn_estimate
 Context.render = _ctx_render

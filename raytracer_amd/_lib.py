@@ -84,6 +84,10 @@ PROTOTYPES = {
     "rt_trace_primary_dev": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, vp, vp, vp, P(Stats)]),
     "rt_trace_primary": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, P(c_i32), P(c_d), P(c_i32), P(Stats)]),
     "rt_photons_upload": (c_i, [vp, c_i, c_i64, P(c_d)]),
+    "rt_photons_upload_dev_build": (c_i, [vp, c_i, c_i64, P(c_d)]),
+    "rt_emit_photon_maps_dev": (c_i, [vp, c_i64, P(c_d), ctypes.c_uint32, c_i, c_d, P(c_i64), P(Stats)]),
+    "rt_photon_map_size": (c_i64, [vp, c_i]),
+    "rt_photon_map_get": (c_i, [vp, c_i, P(c_d)]),
     "rt_knn_radius": (c_i, [vp, c_i, c_i, c_d, c_i64, P(c_d), P(c_i32), P(c_d)]),
     "rt_knn_query": (c_i, [vp, c_i, c_i, c_d, c_i64, P(c_d), P(c_i32), P(c_i32)]),
     "rt_knn_estimate": (c_i, [vp, P(RenderParams), c_i64, P(c_d), P(c_d), P(c_d), P(c_d), P(c_i32)]),

@@ -17,6 +17,7 @@
 #include "rt_kernels.hip.h"
 #include "rt_math.h"
 #include "rt_emit.hip.h"
+#include "rt_kd.hip.h"
 #include "rt_lbvh.hip.h"
 #include "rt_render.hip.h"
 
@@ -93,6 +94,9 @@ struct rt_context {
     DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
     // photon maps in HBM (0 surface, 1 volume)
     DevBuf ph_pos[2], ph_aux[2], ph_axis[2], ph_order[2], ph_box[2];
+    DevBuf ph_src[2];         // photon records (9 doubles each) of a map built on the device, in list order
+    int64_t ph_src_n[2] = {0, 0};
+    DevBuf ph_raw[2], kd_work;   // emission output before ordering; working set of the device build
     rtg::PhotonMapView pm[2] = {};
     // render queues
     DevBuf hits_a, hits_b, rays, gq, acc;
@@ -271,7 +275,8 @@ void rt_context_destroy(rt_context* ctx)
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
                       &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
-                      &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1], &ctx->ph_box[0], &ctx->ph_box[1]})
+                      &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1], &ctx->ph_box[0], &ctx->ph_box[1], &ctx->ph_src[0], &ctx->ph_src[1],
+                      &ctx->ph_raw[0], &ctx->ph_raw[1], &ctx->kd_work})
         b->release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -437,14 +442,15 @@ int rt_scene_emit_photons(rt_scene* s, int64_t n_emit, const double light_pos[3]
     rth::emit_photons(s->s, n_emit, light_pos, seed, ep, s->photons[0], s->photons[1]);
     return RT_OK;
 }
-int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy,
-                              rt_stats* stats)
+}  // extern "C"
+namespace {
+
+// The emission kernel over batches of 2^20 photons.  After each batch, `sink(which, records, count)` is
+// called for every non-empty queue shard (device pointer; the stream is idle at that point).
+template <class Sink>
+int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy, rt_stats* stats, Sink sink)
 {
-    if (!ctx || !s || !light_pos || n_emit < 0 || bounce < 0 || bounce > 7) return fail(RT_ERR_INVALID, "bad argument");
-    if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
-    if ((int64_t)s->s.objects.size() != ctx->n_objects) return fail(RT_ERR_STATE, "the scene is not the one uploaded to this context");
     int rc;
-    if ((rc = use_device(ctx))) return rc;
     const int cap = stack_cap(ctx);
     const size_t lds = rtk::stack_lds_bytes(cap, sizeof(double));
     if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
@@ -455,7 +461,6 @@ int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, cons
     if ((rc = ctx->hits_a.reserve(cap_s * rtq::SHARDS * sizeof(rte::PhotonOut)))) return rc;
     if ((rc = ctx->hits_b.reserve(cap_v * rtq::SHARDS * sizeof(rte::PhotonOut)))) return rc;
     if ((rc = ctx->counters.reserve(sizeof(rte::EmitCounters)))) return rc;
-    std::vector<rte::PhotonOut> host[2];
     rte::ShadeTables sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     rte::EmitCounters* ctr = (rte::EmitCounters*)ctx->counters.p;
     uint64_t rays = 0;
@@ -489,14 +494,113 @@ int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, cons
             const rte::PhotonOut* dev = (const rte::PhotonOut*)(which ? ctx->hits_b.p : ctx->hits_a.p);
             for (int sh = 0; sh < rtq::SHARDS; sh++) {
                 size_t n = (size_t)std::min<unsigned long long>(c.n[sh][0], shard_cap);
-                if (!n) continue;
-                size_t at = host[which].size();
-                host[which].resize(at + n);
-                HIP_TRY(hipMemcpyAsync(host[which].data() + at, dev + (size_t)sh * shard_cap, n * sizeof(rte::PhotonOut), hipMemcpyDeviceToHost, ctx->stream));
+                if (n && (rc = sink(which, dev + (size_t)sh * shard_cap, n))) return rc;
             }
         }
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        stats->secondary_rays = rays;
+        stats->kernel_ms = stats->trace_kernel_ms = ms_total;
+    }
+    return RT_OK;
+}
+
+// keeps the first `used` bytes across a growth of the buffer
+int grow_keep(DevBuf& b, size_t need, size_t used, hipStream_t stream)
+{
+    if (need <= b.bytes) return RT_OK;
+    DevBuf bigger;
+    int rc = bigger.reserve(std::max(need, b.bytes * 2));
+    if (rc) return rc;
+    if (used) {
+        HIP_TRY(hipMemcpyAsync(bigger.p, b.p, used, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    b.release();
+    b = bigger;
+    return RT_OK;
+}
+
+// Photon map `which` from n records on the device (9 doubles every `stride` doubles; must not live in
+// ctx->kd_work).  Kdtree.cpp:11-52 restated level by level, see rt_kd.hip.h.
+int build_photon_map_dev(rt_context* ctx, int which, long long n, const double* d_rec, int stride)
+{
+    int rc;
+    if (n >= (1ll << 31)) return fail(RT_ERR_LIMIT, "photon count %lld exceeds 2^31", n);
+    rtg::PhotonMapView& pm = ctx->pm[which];
+    if ((rc = ctx->ph_pos[which].reserve(std::max<size_t>(64, (size_t)n * 16)))) return rc;
+    if ((rc = ctx->ph_aux[which].reserve(std::max<size_t>(64, (size_t)n * 24)))) return rc;
+    if ((rc = ctx->ph_order[which].reserve(std::max<size_t>(64, (size_t)n * 4)))) return rc;
+    if ((rc = ctx->ph_box[which].reserve((size_t)(n / 32 + 1) * 24))) return rc;
+    pm.pos = (const float4*)ctx->ph_pos[which].p;
+    pm.aux = (const float*)ctx->ph_aux[which].p;
+    pm.order = (const int*)ctx->ph_order[which].p;
+    pm.leaf_box = (const float*)ctx->ph_box[which].p;
+    pm.n = n;
+    if (n == 0) return RT_OK;
+    const int ni = (int)n;
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t at = off; off += align(bytes); return at; };
+    const size_t n_bounds = (size_t)(n / 32 + 2) * 3;
+    const size_t o_k0 = carve(n * 8), o_k1 = carve(n * 8), o_v0 = carve(n * 4), o_v1 = carve(n * 4), o_ax = carve(n), o_mn = carve(n_bounds * 4),
+                 o_mx = carve(n_bounds * 4);
+    size_t sort_bytes = 0;
+    const int levels = rtkd::levels_for(n);
+    int key_bits = 33;
+    while (key_bits < 64 && (n >> (key_bits - 32)) != 0) key_bits++;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
+                                               (unsigned*)nullptr, ni, 0, key_bits, ctx->stream));
+    const size_t o_tmp = carve(sort_bytes + 256);
+    if ((rc = ctx->kd_work.reserve(off))) return rc;
+    char* w = (char*)ctx->kd_work.p;
+    auto* k0 = (unsigned long long*)(w + o_k0); auto* k1 = (unsigned long long*)(w + o_k1);
+    auto* v0 = (unsigned*)(w + o_v0); auto* v1 = (unsigned*)(w + o_v1);
+    auto* axis_at = (unsigned char*)(w + o_ax); auto* mins = (unsigned*)(w + o_mn); auto* maxs = (unsigned*)(w + o_mx);
+    const int T = 256;
+    const dim3 grid((unsigned)((n + T - 1) / T));
+    rtkd::Source src{d_rec, stride};
+    hipLaunchKernelGGL(rtkd::iota_kernel, grid, dim3(T), 0, ctx->stream, ni, v0);
+    HIP_TRY(hipMemsetAsync(axis_at, 0, (size_t)n, ctx->stream));
+    for (int level = 0; level < levels; level++) {
+        const size_t used = std::min(n_bounds, (size_t)3 << level);
+        HIP_TRY(hipMemsetAsync(mins, 0xFF, used * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(maxs, 0, used * 4, ctx->stream));
+        hipLaunchKernelGGL(rtkd::bounds_kernel, grid, dim3(T), 0, ctx->stream, src, ni, level, (const unsigned*)v0, mins, maxs);
+        hipLaunchKernelGGL(rtkd::key_kernel, grid, dim3(T), 0, ctx->stream, src, ni, level, (const unsigned*)v0, (const unsigned*)mins, (const unsigned*)maxs, k0,
+                           axis_at);
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + o_tmp, sort_bytes, k0, k1, v0, v1, ni, 0, key_bits, ctx->stream));
+        std::swap(v0, v1);
+    }
+    hipLaunchKernelGGL(rtkd::emit_kernel, grid, dim3(T), 0, ctx->stream, src, ni, (const unsigned*)v0, (const unsigned char*)axis_at,
+                       (float4*)ctx->ph_pos[which].p, (float*)ctx->ph_aux[which].p, (int*)ctx->ph_order[which].p);
+    hipLaunchKernelGGL(rtkd::leaf_box_kernel, grid, dim3(T), 0, ctx->stream, ni, levels, (const float4*)ctx->ph_pos[which].p, (float*)ctx->ph_box[which].p);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+extern "C" {
+
+int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy,
+                              rt_stats* stats)
+{
+    if (!ctx || !s || !light_pos || n_emit < 0 || bounce < 0 || bounce > 7) return fail(RT_ERR_INVALID, "bad argument");
+    if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
+    if ((int64_t)s->s.objects.size() != ctx->n_objects) return fail(RT_ERR_STATE, "the scene is not the one uploaded to this context");
+    int rc;
+    if ((rc = use_device(ctx))) return rc;
+    std::vector<rte::PhotonOut> host[2];
+    rc = emit_batches(ctx, n_emit, light_pos, seed, bounce, accuracy, stats, [&](int which, const rte::PhotonOut* dev, size_t n) {
+        size_t at = host[which].size();
+        host[which].resize(at + n);
+        HIP_TRY(hipMemcpyAsync(host[which].data() + at, dev, n * sizeof(rte::PhotonOut), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));     // the vector may move at the next call
+        return (int)RT_OK;
+    });
+    if (rc) return rc;
     for (int which = 0; which < 2; which++) {
         std::vector<uint32_t> order(host[which].size());
         for (size_t i = 0; i < order.size(); i++) order[i] = (uint32_t)i;
@@ -510,13 +614,94 @@ int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, cons
             out.push_back(r);
         }
     }
+    return RT_OK;
+}
+
+int rt_emit_photon_maps_dev(rt_context* ctx, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy, int64_t counts[2],
+                            rt_stats* stats)
+{
+    if (!ctx || !light_pos || n_emit < 0 || bounce < 0 || bounce > 7) return fail(RT_ERR_INVALID, "bad argument");
+    if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
+    int rc;
+    if ((rc = use_device(ctx))) return rc;
+    static_assert(sizeof(rte::PhotonOut) == 80, "PhotonOut is 9 doubles and a key");
+    size_t got[2] = {0, 0};
+    rt_stats est;
+    rc = emit_batches(ctx, n_emit, light_pos, seed, bounce, accuracy, &est, [&](int which, const rte::PhotonOut* dev, size_t n) {
+        int r = grow_keep(ctx->ph_raw[which], (got[which] + n) * sizeof(rte::PhotonOut), got[which] * sizeof(rte::PhotonOut), ctx->stream);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync((rte::PhotonOut*)ctx->ph_raw[which].p + got[which], dev, n * sizeof(rte::PhotonOut), hipMemcpyDeviceToDevice, ctx->stream));
+        got[which] += n;
+        return (int)RT_OK;
+    });
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    for (int which = 0; which < 2; which++) {
+        const long long n = (long long)got[which];
+        if (n >= (1ll << 31)) return fail(RT_ERR_LIMIT, "photon count %lld exceeds 2^31", n);
+        if ((rc = ctx->ph_src[which].reserve(std::max<size_t>(64, (size_t)n * 72)))) return rc;
+        ctx->ph_src_n[which] = n;
+        if (n > 0) {
+            // launch-independent order: by (photon, bounce, slot)
+            const int ni = (int)n;
+            size_t sort_bytes = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
+                                                       (unsigned*)nullptr, ni, 0, 64, ctx->stream));
+            const size_t a8 = ((size_t)n * 8 + 255) & ~(size_t)255, a4 = ((size_t)n * 4 + 255) & ~(size_t)255;
+            if ((rc = ctx->kd_work.reserve(2 * a8 + 2 * a4 + sort_bytes + 256))) return rc;
+            char* w = (char*)ctx->kd_work.p;
+            auto* k0 = (unsigned long long*)w; auto* k1 = (unsigned long long*)(w + a8);
+            auto* v0 = (unsigned*)(w + 2 * a8); auto* v1 = (unsigned*)(w + 2 * a8 + a4);
+            const int T = 256;
+            const double* raw = (const double*)ctx->ph_raw[which].p;
+            hipLaunchKernelGGL(rtkd::gather_keys_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, ctx->stream, ni, raw, 10, 9, k0, v0);
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + 2 * a8 + 2 * a4, sort_bytes, k0, k1, v0, v1, ni, 0, 64, ctx->stream));
+            hipLaunchKernelGGL(rtkd::permute_kernel, dim3((unsigned)((n * 9 + T - 1) / T)), dim3(T), 0, ctx->stream, ni, (const unsigned*)v1, raw, 10,
+                               (double*)ctx->ph_src[which].p);
+            HIP_TRY(hipGetLastError());
+        }
+        if ((rc = build_photon_map_dev(ctx, which, n, (const double*)ctx->ph_src[which].p, 9))) return rc;
+        if (counts) counts[which] = n;
+    }
+    HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (stats) {
-        memset(stats, 0, sizeof *stats);
-        stats->secondary_rays = rays;
-        stats->kernel_ms = stats->trace_kernel_ms = ms_total;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+        *stats = est;
+        stats->kernel_ms = est.trace_kernel_ms + ms;     // emission + ordering + both tree builds
     }
     return RT_OK;
 }
+
+int rt_photons_upload_dev_build(rt_context* ctx, int which, int64_t n, const double* photons)
+{
+    if (!ctx || (which != 0 && which != 1) || n < 0 || (n > 0 && !photons)) return fail(RT_ERR_INVALID, "bad argument");
+    if (n >= (1ll << 31)) return fail(RT_ERR_LIMIT, "photon count %lld exceeds 2^31", (long long)n);
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if ((rc = ctx->ph_src[which].reserve(std::max<size_t>(64, (size_t)n * 72)))) return rc;
+    ctx->ph_src_n[which] = n;
+    if (n) HIP_TRY(hipMemcpyAsync(ctx->ph_src[which].p, photons, (size_t)n * 72, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = build_photon_map_dev(ctx, which, n, (const double*)ctx->ph_src[which].p, 9))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));     // the caller's buffer is free again
+    return RT_OK;
+}
+
+int64_t rt_photon_map_size(const rt_context* ctx, int which) { return (ctx && (which == 0 || which == 1)) ? (int64_t)ctx->pm[which].n : -1; }
+
+int rt_photon_map_get(rt_context* ctx, int which, double* photons)
+{
+    if (!ctx || (which != 0 && which != 1) || !photons) return fail(RT_ERR_INVALID, "bad argument");
+    if (ctx->ph_src_n[which] != ctx->pm[which].n) return fail(RT_ERR_STATE, "photon map %d was not built on the device", which);
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    if (ctx->ph_src_n[which])
+        HIP_TRY(hipMemcpyAsync(photons, ctx->ph_src[which].p, (size_t)ctx->ph_src_n[which] * 72, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
 int64_t rt_scene_photon_count(const rt_scene* s, int which) { return (s && (which == 0 || which == 1)) ? (int64_t)s->photons[which].size() : -1; }
 int rt_scene_photons_get(const rt_scene* s, int which, double* photons)
 {
@@ -850,6 +1035,7 @@ int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photo
     ctx->pm[which].order = (const int*)ctx->ph_order[which].p;
     ctx->pm[which].leaf_box = (const float*)ctx->ph_box[which].p;
     ctx->pm[which].n = n;
+    ctx->ph_src_n[which] = -1;
     return RT_OK;
 }
 

@@ -776,7 +776,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                         vc = knn_collect(vm, (float)px, (float)py, (float)pz, gp.k, gp.r2, gp.front_cap, pf);
                         __builtin_amdgcn_wave_barrier();
                         volume_step(vm, vc, hp, r.color, e_pass, gp.photon_num, sss);
-                        double d = -log(unit_random(r.pixel, (uint32_t)(q * 2 + pass), gp.seed)) / 200;   // main.cpp:374
+                        // the stream is keyed by what identifies the request whatever the launch: pixel, hit point, pass
+                        const uint32_t where = __float_as_uint(hp[0]) * 0x9E3779B1u ^ __float_as_uint(hp[1]) * 0x85EBCA77u ^ __float_as_uint(hp[2]) * 0xC2B2AE3Du;
+                        double d = -log(unit_random(r.pixel, where + (uint32_t)pass, gp.seed)) / 200;   // main.cpp:374
                         px += r.march[0] * d; py += r.march[1] * d; pz += r.march[2] * d;
                         e_pass *= 2.71828;
                     }

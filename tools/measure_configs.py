@@ -59,6 +59,17 @@ def main():
         t1 = time.perf_counter()
         print(f"C4 GPU emission: {nemit} -> {s.photon_count(0)} photons, {est.secondary_rays} rays, kernels {est.kernel_ms:.2f} ms, "
               f"wall incl. download and ordering {t1 - t0:.3f} s")
+        ph = s.photons_get()
+        for name, fn in (("host", ctx.photons_upload), ("device", ctx.photons_upload_dev_build)):
+            fn(ph)
+            t0 = time.perf_counter()
+            fn(ph)
+            print(f"C4 kd-tree of {len(ph)} photons, {name} build incl. upload: {(time.perf_counter() - t0) * 1e3:.1f} ms")
+        for _ in range(2):
+            t0 = time.perf_counter()
+            (ns, nv), est = ctx.emit_photon_maps(nemit, seed=12345)
+            t1 = time.perf_counter()
+        print(f"C4 emission + ordering + kd-trees on the device: {ns} photons, kernels {est.kernel_ms:.2f} ms (emission {est.trace_kernel_ms:.2f}), wall {(t1 - t0) * 1e3:.1f} ms")
         for k in (1000, 100):
             p = rt.default_params(width=1920, height=1080, photon_num=nemit, photon_use=k)
             st, dt = timed_render(ctx, p, reps=2)
