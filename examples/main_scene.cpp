@@ -4,7 +4,8 @@
 // (photon emission, per-pixel ray trace) handed to Renderer, which runs the pixel loop on the GPU.
 //
 //   main_scene <mesh.obj> <out.bmp> [width height photons seed special ior yoff]
-//   RT_DEVICE_TREE=1 builds the BVH on the GPU instead of the reference's tree on the host.
+//   RT_DEVICE_TREE=1 builds the BVH and the photon kd-tree on the GPU instead of the reference's
+//   trees on the host.
 #include "../raytracer_amd/scene/System.h"
 
 #include "../raytracer_amd/scene/BVH.h"
@@ -70,7 +71,7 @@ int main(int argc, char* argv[])
 
     Renderer renderer(bvh);
     renderer.emitPhotons(photon_count, scene_light.getLightPosition(), seed, photons, volumePhotons);
-    kdtree = new KDTree(photons);
+    kdtree = new KDTree(photons, 0, device_tree && atoi(device_tree) != 0);
 
     // one probe through the single-ray API, as main.cpp's loops would issue it
     double d = 1e9;

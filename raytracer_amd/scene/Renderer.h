@@ -45,6 +45,18 @@ public:
         }
     }
 
+    // main.cpp:683-727 in one call that never leaves the GPU: emission (the on_device streams above),
+    // both photon lists in emission order and both kd-trees; nothing comes back to the host, so no
+    // KDTree object is needed before render().  Returns the photons stored in the surface map.
+    long long emitPhotonMaps(long long n_emit, Vect light_position, unsigned seed, int bounce = 5, double accuracy = 0.000001,
+                             long long* volume_count = nullptr)
+    {
+        int64_t counts[2] = {0, 0};
+        rt::check(rt_emit_photon_maps_dev(rt::device(), n_emit, light_position.data(), seed, bounce, accuracy, counts, nullptr), "rt_emit_photon_maps_dev");
+        if (volume_count) *volume_count = counts[1];
+        return counts[0];
+    }
+
     // the pixel loop: pixels[y * width + x], y = 0 is the bottom BMP row (main.cpp:739,758)
     rt_stats render(const Camera& cam, const rt_render_params& params, RGBType* pixels)
     {
