@@ -88,6 +88,7 @@ typedef struct rt_stats {
     uint64_t prim_tests;      /* findIntersection calls (only with count_work) */
     double kernel_ms;         /* device time of the call measured with HIP events on the context's stream */
     double trace_kernel_ms;   /* device time of the traversal kernel launches only */
+    uint64_t gather_single;   /* of gather_queries: answered one per wave (subsurface hits, groups the grouped form handed over) */
 } rt_stats;
 
 /* ---- process / context ------------------------------------------------------------------- */
@@ -221,6 +222,13 @@ int rt_knn_query(rt_context* ctx, int which, int k, double max_dist, int64_t n, 
  * pos/normal n x 3, color n x 3 (hit colour), rgb out n x 3 (clipped as Color::clip) */
 int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal,
                     const double* color, double* rgb, int32_t* counts);
+
+/* The same estimate through the form the pixel path uses: requests are taken in groups of 64
+ * consecutive ones (as one shading wave queues them) and answered one per lane over a photon list
+ * shared by the group; requests a group cannot take fall to the per-request form above.  Same
+ * k-nearest sets, sums in another order. */
+int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal,
+                            const double* color, double* rgb);
 
 /* ---- device: full pixel path ------------------------------------------------------------- */
 /* The pixel loop of main.cpp:735-861 for rows [row_begin,row_end): primary rays, BVH::Shoot,

@@ -263,6 +263,15 @@ def _ctx_knn_estimate(self, params, pos, normal, color):
     return rgb, cnt
 
 
+def _ctx_knn_estimate_grouped(self, params, pos, normal, color):
+    """knn_estimate through the grouped gather of the pixel path (64 consecutive requests per wave)."""
+    pos = _f64(pos); normal = _f64(normal); color = _f64(color)
+    n = pos.shape[0]
+    rgb = np.zeros((n, 3))
+    _chk(lib.rt_knn_estimate_grouped(self.h, ctypes.byref(params), n, _dp(pos), _dp(normal), _dp(color), _dp(rgb)), "rt_knn_estimate_grouped")
+    return rgb
+
+
 def _ctx_render(self, cam, params, rows=None):
     """Full pixel path for a row block: returns (rgb float64 [rows, w, 3], bgr8 uint8 [rows, w, 3], Stats)."""
     part_rows = params.height // params.n_parts if params.band_rows > 0 else params.height
@@ -290,6 +299,7 @@ Context.photon_map_get = _ctx_photon_map_get
 Context.knn_query = _ctx_knn_query
 Context.knn_radius = _ctx_knn_radius
 Context.knn_estimate = _ctx_knn_estimate
+Context.knn_estimate_grouped = _ctx_knn_estimate_grouped
 Context.render = _ctx_render
 Context.render_dev = _ctx_render_dev
 

@@ -38,7 +38,7 @@ class RenderParams(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [
         ("primary_rays", ctypes.c_uint64), ("secondary_rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64),
-        ("gather_queries", ctypes.c_uint64), ("inner_visits", ctypes.c_uint64), ("prim_tests", ctypes.c_uint64), ("kernel_ms", c_d), ("trace_kernel_ms", c_d),
+        ("gather_queries", ctypes.c_uint64), ("inner_visits", ctypes.c_uint64), ("prim_tests", ctypes.c_uint64), ("kernel_ms", c_d), ("trace_kernel_ms", c_d), ("gather_single", ctypes.c_uint64),
     ]
 
 
@@ -91,6 +91,7 @@ PROTOTYPES = {
     "rt_knn_radius": (c_i, [vp, c_i, c_i, c_d, c_i64, P(c_d), P(c_i32), P(c_d)]),
     "rt_knn_query": (c_i, [vp, c_i, c_i, c_d, c_i64, P(c_d), P(c_i32), P(c_i32)]),
     "rt_knn_estimate": (c_i, [vp, P(RenderParams), c_i64, P(c_d), P(c_d), P(c_d), P(c_d), P(c_i32)]),
+    "rt_knn_estimate_grouped": (c_i, [vp, P(RenderParams), c_i64, P(c_d), P(c_d), P(c_d), P(c_d)]),
     "rt_render_rows_dev": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, vp, vp, P(Stats)]),
     "rt_render_rows": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, P(c_d), P(c_u8), P(Stats)]),
     "rt_save_bmp": (c_i, [ctypes.c_char_p, c_i, c_i, c_i, P(c_d)]),

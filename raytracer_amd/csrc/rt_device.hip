@@ -13,7 +13,7 @@
 #include "host_photon.h"
 #include "host_scene.h"
 #include "rt_flat.h"
-#include "rt_gather.hip.h"
+#include "rt_gather_tile.hip.h"
 #include "rt_kernels.hip.h"
 #include "rt_math.h"
 #include "rt_emit.hip.h"
@@ -99,7 +99,7 @@ struct rt_context {
     DevBuf ph_raw[2], kd_work;   // emission output before ordering; working set of the device build
     rtg::PhotonMapView pm[2] = {};
     // render queues
-    DevBuf hits_a, hits_b, rays, gq, acc;
+    DevBuf hits_a, hits_b, rays, gq, acc, redo;
     // staging for the host-buffer convenience entry points
     DevBuf st_org, st_dir, st_dist, st_ids, st_aux;
 };
@@ -274,7 +274,7 @@ void rt_context_destroy(rt_context* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
-                      &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
+                      &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->redo, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
                       &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1], &ctx->ph_box[0], &ctx->ph_box[1], &ctx->ph_src[0], &ctx->ph_src[1],
                       &ctx->ph_raw[0], &ctx->ph_raw[1], &ctx->kd_work})
         b->release();
@@ -1124,6 +1124,88 @@ int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const
 }  // extern "C"
 
 namespace {
+int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
+                  unsigned long long* n_redo, unsigned long long* next_gather, const rtg::GatherParams& gp, double* d_acc);
+}
+extern "C" {
+
+int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal, const double* color,
+                            double* rgb)
+{
+    if (!ctx || !pos || !normal || !color || !rgb || n < 0) return fail(RT_ERR_INVALID, "bad argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (p->photon_use < 1 || p->photon_use > rtg::MAX_K) return fail(RT_ERR_LIMIT, "photon_use %d outside [1,%d]", p->photon_use, rtg::MAX_K);
+    if (n == 0) return RT_OK;
+    if (n >= (1ll << 31)) return fail(RT_ERR_LIMIT, "%lld requests", (long long)n);
+    if ((rc = use_device(ctx))) return rc;
+    // the requests as the shading kernel would queue them: windows of 64 in one shard
+    const size_t slots = (size_t)((n + 63) / 64) * 64;
+    std::vector<rtg::GatherRec> recs(slots);
+    memset(recs.data(), 0, slots * sizeof(rtg::GatherRec));
+    for (int64_t i = 0; i < n; i++) {
+        rtg::GatherRec& g = recs[(size_t)i];
+        for (int c = 0; c < 3; c++) { g.pos[c] = pos[3 * i + c]; g.normal[c] = normal[3 * i + c]; g.color[c] = color[3 * i + c]; }
+        g.weight = 1.0;
+        g.pixel = (uint32_t)i;
+        if (i % 64 == 0) g.flags = (uint32_t)std::min<int64_t>(64, n - i) << rtg::GATHER_COUNT_SHIFT;
+    }
+    if ((rc = upload(ctx->gq, recs, ctx->stream))) return rc;
+    if ((rc = ctx->redo.reserve(slots * sizeof(uint32_t)))) return rc;
+    if ((rc = ctx->acc.reserve((size_t)n * 3 * sizeof(double)))) return rc;
+    rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
+    const unsigned long long n_slots = slots;
+    HIP_TRY(hipMemcpyAsync(&ctr->gather.n[0][0], &n_slots, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->acc.p, 0, (size_t)n * 3 * sizeof(double), ctx->stream));
+    rtg::GatherParams gp;
+    gp.front_cap = gather_front_cap();
+    gp.k = p->photon_use;
+    gp.r2 = (float)(p->photon_dist * p->photon_dist);
+    gp.norm = (double)(p->photon_num / 16) * 3.1415926;
+    gp.photon_num = (double)p->photon_num;
+    gp.seed = 12345u;
+    if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp,
+                            (double*)ctx->acc.p)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(rgb, ctx->acc.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));    // also: `recs` and `n_slots` die at return
+    return RT_OK;
+}
+}  // extern "C"
+
+namespace {
+
+// The gather over a queue of request windows: the group kernel, then the per-request kernel for what it
+// left.  RT_GATHER_MODE=query hands every request to the per-request kernel (comparison runs).
+int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
+                  unsigned long long* n_redo, unsigned long long* next_gather, const rtg::GatherParams& gp, double* d_acc)
+{
+    const char* mode = getenv("RT_GATHER_MODE");
+    // RT_GATHER_PROF=1: per-phase cycle totals of the group kernel, printed to stderr (development aid)
+    const bool prof = getenv("RT_GATHER_PROF") != nullptr;
+    int rc;
+    if (prof && (rc = ctx->st_aux.reserve(rtg::TP_SLOTS * 8))) return rc;
+    if (prof) HIP_TRY(hipMemsetAsync(ctx->st_aux.p, 0, rtg::TP_SLOTS * 8, ctx->stream));
+    rtg::TileArgs ta{recs, cnt, shard_cap, next_window, (uint32_t*)ctx->redo.p, n_redo, (mode && mode[0] == 'q') ? 1 : 0,
+                     prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
+    hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gp, d_acc);
+    HIP_TRY(hipGetLastError());
+    if (prof) {
+        unsigned long long v[rtg::TP_SLOTS];
+        HIP_TRY(hipMemcpyAsync(v, ctx->st_aux.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const double nr = (double)std::max<unsigned long long>(1, v[rtg::TP_ROUNDS]);
+        fprintf(stderr, "group gather (k=%d): %llu windows, %llu rounds, %.1f requests and %.1f steps of 64 photons per round; cycles per round: "
+                        "kth %.0f, walk %.0f, hist %.0f, crit %.0f, rank %.0f, sum %.0f\n",
+                gp.k, v[rtg::TP_WINDOWS], v[rtg::TP_ROUNDS], v[rtg::TP_LANES] / nr, v[rtg::TP_STEPS] / nr, v[rtg::TP_KTH] / nr, v[rtg::TP_WALK] / nr,
+                v[rtg::TP_HIST] / nr, v[rtg::TP_CRIT] / nr, v[rtg::TP_RANK] / nr, v[rtg::TP_SUM] / nr);
+    }
+    hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, (const uint32_t*)ctx->redo.p,
+                       (const unsigned long long*)n_redo, next_gather, gp, d_acc);
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
 
 // the three traversal kernels of the render path for one (R, TRI_ONLY, MODE) choice
 template <class R, bool TRI_ONLY, int MODE>
@@ -1168,13 +1250,15 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     // worst case: every hit of a level spawns two (reflection + refraction); the queues are split into
     // shards of equal capacity that fill nearly evenly (producers pick shards round-robin), with slack
     const unsigned long long cap_hits = samples << std::max(0, std::min(levels - 1, 3));
-    const unsigned long long shard_cap = (cap_hits + rtq::SHARDS - 1) / rtq::SHARDS + 16384;
+    // (a multiple of 64: the gather queue is filled in whole windows of 64 slots)
+    const unsigned long long shard_cap = (((cap_hits + rtq::SHARDS - 1) / rtq::SHARDS + 16384) + 63) & ~63ull;
     const unsigned long long cap_total = shard_cap * rtq::SHARDS;
     int rc;
     if ((rc = ctx->hits_a.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
     if ((rc = ctx->hits_b.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
     if ((rc = ctx->rays.reserve(cap_total * sizeof(rtr::RayRec)))) return rc;
     if ((rc = ctx->gq.reserve(cap_total * sizeof(rtg::GatherRec)))) return rc;
+    if ((rc = ctx->redo.reserve(cap_total * sizeof(uint32_t)))) return rc;
     TraceGeom g;
     if ((rc = trace_geometry<R>(ctx, ctx->n_nodes, &g))) return rc;
     rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
@@ -1201,9 +1285,8 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
         gp.norm = (double)(p->photon_num / 16) * 3.1415926;
         gp.photon_num = (double)p->photon_num;
         gp.seed = 12345u;
-        hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], (const rtg::GatherRec*)ctx->gq.p,
-                           &ctr->gather, shard_cap, &ctr->next_gather, gp, d_acc);
-        HIP_TRY(hipGetLastError());
+        if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, shard_cap, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp, d_acc)))
+            return rc;
     }
     if (host_ctr) HIP_TRY(hipMemcpyAsync(host_ctr, ctr, sizeof(*host_ctr), hipMemcpyDeviceToHost, ctx->stream));
     return RT_OK;
@@ -1270,7 +1353,8 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
             if (hc[i].overflow_stack) return fail(RT_ERR_LIMIT, "traversal stack overflow");
             if (hc[i].overflow_queue) return fail(RT_ERR_LIMIT, "bounce/gather queue overflow");
             total.secondary_rays += hc[i].secondary_rays;
-            for (int sh = 0; sh < rtq::SHARDS; sh++) total.gather_queries += hc[i].gather.n[sh][0];
+            for (int sh = 0; sh < rtq::SHARDS; sh++) total.gather_queries += hc[i].gather.n[sh][1];
+            total.gather_single += hc[i].n_redo;
         }
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));

@@ -728,18 +728,20 @@ __device__ __forceinline__ double unit_random(uint32_t a, uint32_t b, uint32_t s
     return ((double)x + 0.5) * (1.0 / 4294967296.0);
 }
 
-// Gather queue consumer: acc[3*pixel..] += weight * clip(estimate).  One request per wave at a time.
-// Requests differ a lot in cost, so the (single-wave) blocks of the persistent grid draw them from
-// a shared counter -- several per draw while plenty are left, one near the end; a request takes
-// tens of microseconds, which keeps the draw rate far below what one counter word sustains.
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_kernel(PhotonMapView pm, PhotonMapView vm, const GatherRec* __restrict__ recs, const rtq::Counts* cnt,
-                                                      unsigned long long shard_cap, unsigned long long* next, GatherParams gp,
+// Per-request consumer: acc[3*pixel..] += weight * clip(estimate) for the requests whose queue slots
+// are listed in `list` (those the group form hands over: subsurface materials, crowded or
+// incoherent groups).  One request per wave at a time.  Requests differ a lot in cost, so the
+// (single-wave) blocks of the persistent grid draw them from a shared counter -- several per draw
+// while plenty are left, one near the end; a request takes tens of microseconds, which keeps the
+// draw rate far below what one counter word sustains.
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_kernel(PhotonMapView pm, PhotonMapView vm, const GatherRec* __restrict__ recs, const uint32_t* __restrict__ list,
+                                                      const unsigned long long* n_list, unsigned long long* next, GatherParams gp,
                                                       double* __restrict__ acc)
 {
     const int lane = lane_id();
     const Prof pf{nullptr};
-    const rtq::Map map = rtq::map_units(cnt, shard_cap, 1);
-    const uint32_t n = map.total;
+    const unsigned long long n_all = *n_list;
+    const uint32_t n = n_all > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_all;
     uint32_t q_end = 0;
     Neighbour nb{0.f, 0.f, 0.f, -1.f};
     while (true) {
@@ -752,10 +754,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         if (q0 >= n) break;
         q_end = q0 + want < n ? (uint32_t)q0 + want : n;
         for (uint32_t q = (uint32_t)q0; q < q_end; q++) {
-            unsigned shard;
-            uint32_t first, n_shard;
-            rtq::locate(map, q, 1, shard, first, n_shard);
-            const GatherRec& r = recs[(unsigned long long)shard * shard_cap + first];
+            const GatherRec& r = recs[list[q]];
             const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, gp.front_cap, pf, &nb);
             __builtin_amdgcn_wave_barrier();
             double rgb[3];

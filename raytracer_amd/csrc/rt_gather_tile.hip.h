@@ -1,0 +1,533 @@
+// K4, second form: the photon gather for a GROUP of up to 64 neighbouring requests per wave, one
+// request per lane (KDTree::findKNN, Kdtree.cpp:73-158, + the estimate of main.cpp:260-295).
+//
+// The one-query-per-wave form (rt_gather.hip.h) spends its time on bookkeeping around a candidate
+// set in LDS.  Requests appended together by one shading wave are hit points a few pixel footprints
+// apart, whose k-nearest balls overlap almost entirely.  A wave therefore
+//   1. answers ONE request of the group exactly with the per-query machinery; its k-th distance r_c
+//      bounds every other request's by the triangle inequality, r_k(q) <= r_c + |q - q_c|;
+//   2. walks the kd-tree once for the box around all those balls, listing the leaves and inner-node
+//      pivots that touch it;
+//   3. streams the listed photons three times, every lane measuring its own distance to the same
+//      photon (the photon's coordinates travel through scalar registers):
+//        a. a histogram of the squared distances per lane (64 bins over [0, bound_q)) locates the
+//           bin that holds the lane's k-th smallest distance,
+//        b. the distances falling into that bin are kept (a few dozen) and ranked, which gives the
+//           exact k-th distance and how many photons at exactly that distance belong to the set,
+//        c. the radiance estimate is accumulated over the photons of the set, which is never stored.
+// The set is the same exact k-nearest set (ties at the k-th distance broken by list order instead of
+// by buffer order -- arbitrary in both forms and in the reference's heap); the sums run in another
+// order.  Requests the group form does not take (subsurface materials, a crowded bin, a group whose
+// box touches too much of the tree) go to a list the per-query kernel works off afterwards.
+#pragma once
+#include "rt_gather.hip.h"
+
+namespace rtg {
+
+constexpr int T_BINS = 64;        // histogram bins per request
+constexpr int T_CRIT = 48;        // distances of the critical bin kept per request
+constexpr int T_LEAVES = 320;     // leaves a group's box may touch
+constexpr int T_PIVOTS = 512;     // inner-node pivots inside a group's box
+static_assert(T_BINS * WAVE * 4 <= CAP * 8 && T_CRIT * WAVE * 4 <= CAP * 8, "the per-lane tables overlay the candidate buffer");
+static_assert(offsetof(WaveLds, idx) == offsetof(WaveLds, key) + CAP * sizeof(float), "key and idx are one block");
+
+struct TileLds {
+    uint32_t leaf[T_LEAVES];      // first photon << 7 | photons (<= 64): the leaves some request's ball touches
+    uint32_t part[T_LEAVES];      // the subset of them one pass has to look at photon by photon
+    uint32_t piv[T_PIVOTS];       // tree positions of pivots
+};
+__shared__ TileLds g_T;
+
+constexpr uint32_t GATHER_COUNT_SHIFT = 8;    // GatherRec::flags bits 8..14 of a window's first record: requests in the window
+
+// Append the requests of one wave as a window of 64 slots (the group the gather works on).  The
+// first record carries the number of requests.  cnt->n[shard][0] counts slots, [1] requests.
+__device__ __forceinline__ void push_window(GatherRec* q, rtq::Counts* cnt, unsigned long long shard_cap, bool want, GatherRec& rec,
+                                            unsigned long long* overflow)
+{
+    unsigned long long m = __ballot(want);
+    if (m == 0) return;
+    const unsigned shard = rtq::wave_index() & (rtq::SHARDS - 1);
+    const int leader = __builtin_ctzll(m);
+    const unsigned n_req = (unsigned)__builtin_popcountll(m);
+    unsigned long long base = 0;
+    if ((int)rtq::lane_id() == leader) {
+        base = atomicAdd(&cnt->n[shard][0], (unsigned long long)WAVE);
+        atomicAdd(&cnt->n[shard][1], (unsigned long long)n_req);
+        rec.flags |= n_req << GATHER_COUNT_SHIFT;
+    }
+    unsigned lo = __shfl((unsigned)base, leader), hi = __shfl((unsigned)(base >> 32), leader);
+    base = ((unsigned long long)hi << 32) | lo;
+    if (want) {
+        if (base + WAVE <= shard_cap) q[(unsigned long long)shard * shard_cap + base + rtq::prefix_rank(m)] = rec;
+        else *overflow = 1;
+    }
+}
+
+struct TileArgs {
+    const GatherRec* recs;
+    const rtq::Counts* cnt;          // n[s][0]: slots appended to shard s (a multiple of 64)
+    unsigned long long shard_cap;
+    unsigned long long* next;        // draw counter
+    uint32_t* redo;                  // slots of the requests left to the per-query kernel
+    unsigned long long* n_redo;
+    int all_redo;                    // nonzero: hand every request to the per-query kernel (comparison runs)
+    unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
+};
+enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_SLOTS };
+
+__device__ __forceinline__ float bcast(float v, int src) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), src)); }
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// Step s of the group's photon list: the tree position lane j reads (clamped to a valid one) and the
+// number of photons in the step (the same in every lane, returned as a scalar).
+__device__ __forceinline__ int step_index(const uint32_t* leaf, int s, int n_leaf, int n_piv, int lane, int& n)
+{
+    const TileLds& T = g_T;
+    if (s < n_leaf) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf[s]);
+        n = (int)(e & 127u);
+        return (int)(e >> 7) + (lane < n ? lane : n - 1);
+    }
+    const int first = (s - n_leaf) * WAVE;
+    n = n_piv - first < WAVE ? n_piv - first : WAVE;
+    return (int)T.piv[first + (lane < n ? lane : n - 1)];
+}
+
+// the step's photons, lane j holding photon j; lanes beyond the step hold a point no ball reaches, so
+// the loops over a step need no bound checks
+__device__ __forceinline__ float4 step_photons(const float4* __restrict__ pos, const uint32_t* leaf, int s, int n_leaf, int n_piv, int lane, int& n, int& at)
+{
+    at = step_index(leaf, s, n_leaf, n_piv, lane, n);
+    float4 p = pos[at];
+    if (lane >= n) p.x = 1.0e18f;
+    return p;
+}
+
+// k-th nearest distance around one point by the per-query machinery (< 0: fewer than k photons within the radius).
+// Not inlined: its register needs stay out of the group kernel's loops.
+__device__ __attribute__((noinline)) float kth_distance(PhotonMapView pm, float cx, float cy, float cz, int k, float r2, int front_cap)
+{
+    Neighbour nb{0.f, 0.f, 0.f, -1.f};
+    knn_collect(pm, cx, cy, cz, k, r2, front_cap, Prof{nullptr}, &nb);
+    return nb.radius;
+}
+
+// The leaves and pivots inside the box [gl, gh]: fills g_T.leaf / g_T.piv and returns
+// n_leaf | n_piv << 16, or -1 when the box touches more of the tree than the lists hold.
+__device__ __attribute__((noinline)) int group_walk(PhotonMapView pm, float glx, float gly, float glz, float ghx, float ghy, float ghz)
+{
+    WaveLds& L = g_L;
+    TileLds& T = g_T;
+    const int lane = lane_id();
+    int n_leaf = 0, n_piv = 0, nf = 1;
+    if (lane == 0) { L.f_lo[0] = 0; L.f_hi[0] = (int)pm.n; }
+    __builtin_amdgcn_wave_barrier();
+    while (nf > 0) {
+        const int take = nf < WAVE ? nf : WAVE;
+        const int base = nf - take;
+        nf = base;
+        int rlo = 0, rhi = 0;
+        if (lane < take) { rlo = L.f_lo[base + lane]; rhi = L.f_hi[base + lane]; }
+        const bool live = lane < take && rhi > rlo;
+        const bool small = live && rhi - rlo <= WAVE;
+        bool is_leaf = small;
+        if (is_leaf) {
+            const float* b = pm.leaf_box + 6 * (size_t)(rlo >> 5);
+            is_leaf = !(b[0] > ghx || b[3] < glx || b[1] > ghy || b[4] < gly || b[2] > ghz || b[5] < glz);
+        }
+        const bool is_inner = live && !small;
+        int mid = 0;
+        bool piv_in = false, go_l = false, go_r = false;
+        if (is_inner) {
+            mid = rlo + (rhi - rlo) / 2;
+            const float4 pv = pm.pos[mid];
+            const int ax = (int)pv.w;
+            piv_in = !(pv.x > ghx || pv.x < glx || pv.y > ghy || pv.y < gly || pv.z > ghz || pv.z < glz);
+            const float split = ax == 0 ? pv.x : (ax == 1 ? pv.y : pv.z);
+            const float lo_ax = ax == 0 ? glx : (ax == 1 ? gly : glz), hi_ax = ax == 0 ? ghx : (ax == 1 ? ghy : ghz);
+            go_l = lo_ax <= split && mid > rlo;           // the left side holds coordinates <= split
+            go_r = hi_ax >= split && rhi > mid + 1;       // the right side holds coordinates >= split
+        }
+        const unsigned long long m_leaf = __ballot(is_leaf), m_piv = __ballot(piv_in), m_l = __ballot(go_l), m_r = __ballot(go_r);
+        const int c_leaf = __builtin_popcountll(m_leaf), c_piv = __builtin_popcountll(m_piv), c_l = __builtin_popcountll(m_l), c_r = __builtin_popcountll(m_r);
+        __builtin_amdgcn_wave_barrier();
+        if (n_leaf + c_leaf > T_LEAVES || n_piv + c_piv > T_PIVOTS || nf + c_l + c_r > FRONT) return -1;
+        if (is_leaf) T.leaf[n_leaf + (int)prefix_rank(m_leaf)] = ((uint32_t)rlo << 7) | (uint32_t)(rhi - rlo);
+        if (piv_in) T.piv[n_piv + (int)prefix_rank(m_piv)] = (uint32_t)mid;
+        if (go_l) { const int p = nf + (int)prefix_rank(m_l); L.f_lo[p] = rlo; L.f_hi[p] = mid; }
+        if (go_r) { const int p = nf + c_l + (int)prefix_rank(m_r); L.f_lo[p] = mid + 1; L.f_hi[p] = rhi; }
+        n_leaf += c_leaf; n_piv += c_piv; nf += c_l + c_r;
+        __builtin_amdgcn_wave_barrier();
+    }
+    return n_leaf | (n_piv << 16);
+}
+
+// Histogram bin of a squared distance: bin 0 holds everything below `lower` (distances the triangle
+// inequality already puts inside the set), bins 1.. are linear over [lower, bound).  Monotone in d2.
+__device__ __forceinline__ int shell_bin(float d2, float lower, float scale)
+{
+    return (int)__builtin_amdgcn_fmed3f((d2 - lower) * scale + 1.f, 0.f, (float)(T_BINS - 1));
+}
+
+// Copy to `dst` the leaves of `src` that some lane has to look at photon by photon: those with a photon
+// possibly at a squared distance in [lo_lim, hi_lim] from the lane's point (hi_lim < 0: the lane takes no
+// part).  The distance range of a box is taken a little wide, so rounding never drops a leaf that matters.
+// Returns the number kept; `dropped` gets the photons in the leaves left out.  dst may be src.
+// 64 leaves at a time: lane j fetches the j-th box, then every lane measures its own point against each
+// box in turn.
+__device__ __attribute__((noinline)) int select_leaves(const float* __restrict__ leaf_box, const uint32_t* src, uint32_t* dst, float qx, float qy, float qz,
+                                                       float lo_lim, float hi_lim, int n_leaf, int* dropped)
+{
+    const int lane = lane_id();
+    int out = 0, left_out = 0;
+    for (int s0 = 0; s0 < n_leaf; s0 += WAVE) {
+        const int n = n_leaf - s0 < WAVE ? n_leaf - s0 : WAVE;
+        const uint32_t e = src[s0 + (lane < n ? lane : n - 1)];
+        const float* b = leaf_box + 6 * (size_t)((e >> 7) >> 5);
+        const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
+        unsigned long long keep = 0;
+        for (int j = 0; j < n; j++) {
+            const float lx = bcast(b0, j) - qx, hx = qx - bcast(b3, j), ly = bcast(b1, j) - qy, hy = qy - bcast(b4, j), lz = bcast(b2, j) - qz,
+                        hz = qz - bcast(b5, j);
+            const float nx = fmaxf(fmaxf(lx, hx), 0.f), ny = fmaxf(fmaxf(ly, hy), 0.f), nz = fmaxf(fmaxf(lz, hz), 0.f);       // to the nearest point of the box
+            const float fx = fmaxf(-lx, -hx), fy = fmaxf(-ly, -hy), fz = fmaxf(-lz, -hz);                                    // to its farthest corner
+            const float dmin2 = (nx * nx + ny * ny + nz * nz) * 0.9999f, dmax2 = (fx * fx + fy * fy + fz * fz) * 1.0001f;
+            if (__ballot(dmin2 <= hi_lim && dmax2 >= lo_lim)) keep |= 1ull << j;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if ((keep >> lane) & 1ull) dst[out + (int)prefix_rank(keep)] = e;      // out <= s0: never ahead of the entries still to be read
+        if (lane < n && !((keep >> lane) & 1ull)) left_out += (int)(e & 127u);
+        out += __builtin_popcountll(keep);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int off = 32; off > 0; off >>= 1) left_out += __shfl_xor(left_out, off);
+    *dropped = left_out;
+    return out;
+}
+
+__device__ __forceinline__ uint32_t* lane_tables() { return reinterpret_cast<uint32_t*>(g_L.key); }   // [row][lane] over the candidate buffer
+
+// 3a: cell[bin][lane] = photons of the list whose squared distance to the lane's point falls into the bin
+__device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float bound, float lower,
+                                                    float scale, bool act, int n_leaf, int n_piv)
+{
+    uint32_t* const cell = lane_tables();
+    const int lane = lane_id();
+#pragma unroll 8
+    for (int b = 0; b < T_BINS; b++) cell[b * WAVE + lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
+    uint32_t* const mine = cell + lane;
+    uint32_t* const sink = g_L.hist + lane;          // rejected photons count into a row nobody reads
+    const float lim = act ? bound : -1.f;
+    int n = 0, at = 0, n_next = 0;
+    float4 p = n_steps > 0 ? step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_steps; s++, n = n_next) {
+        // the next step's photons are on their way while this step's are used
+        const float4 p_now = p;
+        if (s + 1 < n_steps) p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
+        const int n_now = __builtin_amdgcn_readfirstlane(n);
+        for (int j0 = 0; j0 < n_now; j0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u;
+                const float dx = qx - bcast(p_now.x, j), dy = qy - bcast(p_now.y, j), dz = qz - bcast(p_now.z, j);
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                atomicAdd(d2 < lim ? mine + shell_bin(d2, lower, scale) * WAVE : sink, 1u);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// 3b: cell[i][lane] = the i-th squared distance of the lane that falls into its bin `crit`; returns their number
+__device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float bound, float lower,
+                                                   float scale, bool some, int crit, int n_leaf, int n_piv)
+{
+    uint32_t* const cell = lane_tables();
+    const int lane = lane_id();
+    int cnt = 0;
+    const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
+    const float lim = some ? bound : -1.f;
+    int n = 0, at = 0, n_next = 0;
+    float4 p = n_steps > 0 ? step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_steps; s++, n = n_next) {
+        // the next step's photons are on their way while this step's are used
+        const float4 p_now = p;
+        if (s + 1 < n_steps) p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
+        const int n_now = __builtin_amdgcn_readfirstlane(n);
+        for (int j0 = 0; j0 < n_now; j0 += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int j = j0 + u;
+                const float dx = qx - bcast(p_now.x, j), dy = qy - bcast(p_now.y, j), dz = qz - bcast(p_now.z, j);
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const bool hit = d2 < lim && shell_bin(d2, lower, scale) == crit;
+                if (__ballot(hit)) {           // rare: a few dozen photons per request
+                    if (hit && cnt < T_CRIT) {
+                        cell[cnt * WAVE + lane] = __float_as_uint(d2);
+                        cnt++;
+                    }
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
+
+struct Sum3 { double s0, s1, s2; };
+
+// 3c: the sums of main.cpp:262-291 (power * cosine * weight per channel) over the photons with d2 < t_k and the
+// first want_eq with d2 == t_k
+__device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ pos, const float* __restrict__ aux, const uint32_t* leaf, float qx, float qy, float qz, float t_k,
+                                                   int want_eq, bool some, double n0, double n1, double n2, int n_leaf, int n_piv)
+{
+    const int lane = lane_id();
+    const double ln_base = 0.999999327347282;              // 2.71828^x evaluated as exp(x * ln 2.71828)
+    const double denom = 1 - exp(-1.953 * ln_base);
+    const double inv_denom = 1.0 / denom, inv_2max = 1.0 / (2 * (double)t_k);
+    double s0 = 0, s1 = 0, s2 = 0;
+    int eq_seen = 0;
+    const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
+    const float lim = some ? t_k : -1.f;
+    int n = 0, at = 0, n_next = 0;
+    float4 p = float4{0.f, 0.f, 0.f, 0.f};
+    float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+    if (n_steps > 0) {
+        p = step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at);
+        const float* ax = aux + 6 * (size_t)at;
+        b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
+    }
+    for (int s = 0; s < n_steps; s++, n = n_next) {
+        // the next step's photons are on their way while this step's are used
+        const float4 p_now = p;
+        const float a0 = b0, a1 = b1, a2 = b2, a3 = b3, a4 = b4, a5 = b5;
+        if (s + 1 < n_steps) {
+            p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
+            const float* ax = aux + 6 * (size_t)at;
+            b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
+        }
+        const int n_now = __builtin_amdgcn_readfirstlane(n);
+        for (int j0 = 0; j0 < n_now; j0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = j0 + u;
+                const float dx = qx - bcast(p_now.x, j), dy = qy - bcast(p_now.y, j), dz = qz - bcast(p_now.z, j);
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                bool in = d2 < lim;
+                if (d2 == lim) { in = eq_seen < want_eq; eq_seen++; }
+                if (__ballot(in)) {
+                    const float pr = bcast(a0, j), pg = bcast(a1, j), pb = bcast(a2, j), ux = bcast(a3, j), uy = bcast(a4, j), uz = bcast(a5, j);
+                    if (in) {
+                        // gaussian filter, main.cpp:279 (float result of a double expression; the exponential in single precision)
+                        float weight = (float)(0.918 * (1 - (1 - (double)__expf((float)(((-1.953 * (d2)) * inv_2max) * ln_base))) * inv_denom));
+                        float cosine = (float)(n0 * (-(double)ux) + n1 * (-(double)uy) + n2 * (-(double)uz));   // main.cpp:281-283
+                        if (cosine < 0) cosine = -cosine;
+                        const double sc = (double)(cosine * weight);
+                        s0 += (double)pr * sc;             // main.cpp:286 without the hit colour, which the caller multiplies in
+                        s1 += (double)pg * sc;
+                        s2 += (double)pb * sc;
+                    }
+                }
+            }
+        }
+    }
+    return Sum3{s0, s1, s2};
+}
+
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_tile_kernel(PhotonMapView pm, TileArgs ta, GatherParams gp, double* __restrict__ acc)
+{
+    uint32_t* const cell = lane_tables();
+    const int lane = lane_id();
+    const rtq::Map map = rtq::map_units(ta.cnt, ta.shard_cap, WAVE);
+    const uint32_t n_windows = map.total;
+    unsigned long long pr[TP_SLOTS] = {};
+#define TILE_PROF(slot, expr) do { if (ta.prof) { const unsigned long long t_ = clock64(); expr; pr[slot] += clock64() - t_; } else { expr; } } while (0)
+    while (true) {
+        unsigned long long w0 = 0;
+        if (lane == 0) w0 = atomicAdd(ta.next, 1ull);
+        const uint32_t win = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)w0);
+        const uint32_t win_hi = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(w0 >> 32));
+        if (win_hi || win >= n_windows) break;       // (the high half is zero for any real queue)
+        unsigned shard;
+        uint32_t first, n_shard;
+        rtq::locate(map, win, WAVE, shard, first, n_shard);
+        const unsigned long long slot0 = (unsigned long long)shard * ta.shard_cap + first;
+        const int n_req = (int)((ta.recs[slot0].flags >> GATHER_COUNT_SHIFT) & 127u);
+        const bool have = lane < n_req;
+        const GatherRec& r = ta.recs[slot0 + (have ? lane : 0)];
+        const float qx = (float)r.pos[0], qy = (float)r.pos[1], qz = (float)r.pos[2];
+        const uint32_t flags = r.flags & 0xFFu;
+        bool redo = have && (flags != 0 || ta.all_redo || pm.n >= (1ll << 24));
+        bool todo = have && !redo;
+        pr[TP_WINDOWS]++;
+        // A window mostly holds one patch of neighbouring hit points, but it may hold a few (a tile across a
+        // silhouette, two producers' requests in one window): each round takes the requests close to one of
+        // those still waiting; what is left after ROUNDS rounds, and rounds of only a few requests, go to the
+        // per-request kernel.
+        constexpr int ROUNDS = 4, MIN_LANES = 12;
+        for (int round = 0; round < ROUNDS; round++) {
+            const unsigned long long m_todo = __ballot(todo);
+            if (!m_todo) break;
+            // ---- 1. one request answered exactly: the middle one of those waiting
+            int c_lane = 0;
+            {
+                const int want_rank = __builtin_popcountll(m_todo) / 2;
+                unsigned long long mm = m_todo;
+                for (int i = 0; i < want_rank; i++) mm &= mm - 1;
+                c_lane = __builtin_ctzll(mm);
+            }
+            const float cx = bcast(qx, c_lane), cy = bcast(qy, c_lane), cz = bcast(qz, c_lane);
+            const float ddx = qx - cx, ddy = qy - cy, ddz = qz - cz;
+            const float d_c = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            // a first look at who is near, with the radius unknown: if only a few are within the widest possible
+            // ball they are not worth a round of their own
+            bool act = todo && d_c <= sqrtf(gp.r2);
+            if (__builtin_popcountll(__ballot(act)) < MIN_LANES) {
+                redo = redo || act;
+                todo = todo && !act;
+                continue;
+            }
+            __builtin_amdgcn_wave_barrier();
+            float r_c;
+            TILE_PROF(TP_KTH, r_c = kth_distance(pm, cx, cy, cz, gp.k, gp.r2, gp.front_cap));
+            __builtin_amdgcn_wave_barrier();
+            float bound = gp.r2, lower = 0.f;
+            if (r_c >= 0.f) {
+                act = todo && d_c <= r_c;                            // this round: the requests inside the centre's own ball
+                const float reach = r_c + d_c;
+                const float b = reach * reach * 1.001f + 1e-12f;      // slack for the rounding of the distances
+                if (b < bound) {
+                    bound = b;
+                    // and r_k(q) >= r_c - |q - q_c|: closer photons belong to the set whatever their order
+                    const float inner = fmaxf(r_c - d_c, 0.f);
+                    lower = inner * inner * 0.999f;
+                }
+            }
+            if (__builtin_popcountll(__ballot(act)) < MIN_LANES) {
+                // (the centre itself is always among them, so every round retires at least one request)
+                redo = redo || act;
+                todo = todo && !act;
+                continue;
+            }
+            todo = todo && !act;
+            // ---- 2. the leaves and pivots inside the box around the round's balls
+            const float rad = act ? sqrtf(bound) * 1.0001f + 1e-6f : 0.f;
+            const float big = 3.0e38f;
+            const float glx = wave_min_f(act ? qx - rad : big), gly = wave_min_f(act ? qy - rad : big), glz = wave_min_f(act ? qz - rad : big);
+            const float ghx = wave_max_f(act ? qx + rad : -big), ghy = wave_max_f(act ? qy + rad : -big), ghz = wave_max_f(act ? qz + rad : -big);
+            int lists;
+            TILE_PROF(TP_WALK, lists = group_walk(pm, glx, gly, glz, ghx, ghy, ghz));
+            if (lists < 0) { redo = redo || act; continue; }
+            int n_leaf = lists & 0xFFFF;
+            const int n_piv = lists >> 16;
+            // the walk lists what touches the box around the balls; the corners of that box touch no ball
+            int n_out;
+            n_leaf = select_leaves(pm.leaf_box, g_T.leaf, g_T.leaf, qx, qy, qz, 0.f, act ? bound : -1.f, n_leaf, &n_out);
+            pr[TP_ROUNDS]++; pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_leaf + (n_piv + WAVE - 1) / WAVE;
+
+            const float scale = ((float)(T_BINS - 1) - 0.001f) / (bound - lower);
+            // ---- 3a. per-lane histogram of the squared distances below the lane's bound
+            // leaves that lie inside every request's inner ball count as a whole; the others go photon by photon
+            int n_inside;
+            const int n_hist = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, act ? lower : 3.0e38f, act ? 3.0e38f : -1.f, n_leaf, &n_inside);
+            TILE_PROF(TP_HIST, pass_hist(pm.pos, g_T.part, qx, qy, qz, bound, lower, scale, act, n_hist, n_piv));
+            if (act) cell[lane] += (uint32_t)n_inside;
+            // the bin holding the lane's k-th smallest distance (or its largest, if fewer than k lie within the bound)
+            uint32_t total = 0;
+#pragma unroll 4
+            for (int b = 0; b < T_BINS; b++) total += cell[b * WAVE + lane];
+            const uint32_t k_eff = total < (uint32_t)gp.k ? total : (uint32_t)gp.k;
+            // a bound derived from the neighbour must contain k photons; if it somehow does not, the per-query kernel decides
+            if (act && total < (uint32_t)gp.k && bound < gp.r2) { redo = true; act = false; }
+            int crit = -1;
+            uint32_t below = 0, in_bin = 0;
+            {
+                uint32_t cum = 0;
+#pragma unroll 4
+                for (int b = 0; b < T_BINS; b++) {
+                    const uint32_t h = cell[b * WAVE + lane];
+                    if (crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
+                    cum += h;
+                }
+            }
+            if (act && in_bin > (uint32_t)T_CRIT) { redo = true; act = false; }
+            const bool some = act && k_eff > 0;
+            const int need = (int)(k_eff - below);                 // 1-based rank of the k-th smallest inside its bin
+            __builtin_amdgcn_wave_barrier();
+            // ---- 3b. the distances of that bin, ranked
+            int cnt;
+            // only the leaves that reach into some request's critical shell can hold a distance of its bin
+            const float shell_lo = crit > 0 ? lower + (float)(crit - 1) / scale : 0.f, shell_hi = crit > 0 ? lower + (float)crit / scale : lower;
+            const int n_crit = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, some ? shell_lo * 0.9999f : 3.0e38f, some ? shell_hi * 1.0001f : -1.f, n_leaf,
+                                             &n_out);
+            TILE_PROF(TP_CRIT, cnt = pass_crit(pm.pos, g_T.part, qx, qy, qz, bound, lower, scale, some, crit, n_crit, n_piv));
+            const unsigned long long t_rank = ta.prof ? clock64() : 0ull;
+            const int max_cnt = (int)wave_max_f((float)cnt);
+            uint32_t t_bits = 0;
+            for (int i0 = 0; i0 < max_cnt; i0 += 8) {
+                // eight entries in registers per sweep over the lane's column
+                uint32_t e[8];
+                int rank[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { e[u] = cell[(i0 + u < T_CRIT ? i0 + u : T_CRIT - 1) * WAVE + lane]; rank[u] = 0; }
+                for (int j = 0; j < max_cnt; j++) {
+                    const uint32_t o = cell[j * WAVE + lane];
+                    const bool mine = j < cnt;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) rank[u] += (mine && (o < e[u] || (o == e[u] && j < i0 + u))) ? 1 : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (i0 + u < cnt && rank[u] == need - 1) t_bits = e[u];
+            }
+            int less = 0;
+            for (int j = 0; j < max_cnt; j++) less += (j < cnt && cell[j * WAVE + lane] < t_bits) ? 1 : 0;
+            const float t_k = __uint_as_float(t_bits);             // the k-th distance = maxDistSqr (main.cpp:266-267)
+            const int want_eq = need - less;                       // photons at exactly that distance that belong to the set
+            __builtin_amdgcn_wave_barrier();
+            if (ta.prof) pr[TP_RANK] += clock64() - t_rank;
+            // ---- 3c. the estimate over the set (main.cpp:262-295)
+            Sum3 sum;
+            const unsigned long long t_sum = ta.prof ? clock64() : 0ull;
+            n_leaf = select_leaves(pm.leaf_box, g_T.leaf, g_T.leaf, qx, qy, qz, 0.f, some ? t_k : -1.f, n_leaf, &n_out);      // the final balls are smaller than the bounds
+            sum = pass_sum(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, r.normal[0], r.normal[1], r.normal[2], n_leaf, n_piv);
+            if (ta.prof) pr[TP_SUM] += clock64() - t_sum;
+            if (some) {
+                const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
+                double rgb[3] = {r.color[0] * sum.s0 * sc, r.color[1] * sum.s1 * sc, r.color[2] * sum.s2 * sc};
+                clip3(rgb);                                        // main.cpp:391
+                for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        redo = redo || todo;
+        // ---- requests left to the per-query kernel
+        const unsigned long long m_redo = __ballot(redo);
+        if (m_redo) {
+            unsigned long long at = 0;
+            const int leader = __builtin_ctzll(m_redo);
+            if (lane == leader) at = atomicAdd(ta.n_redo, (unsigned long long)__builtin_popcountll(m_redo));
+            at = ((unsigned long long)(unsigned)__shfl((unsigned)(at >> 32), leader) << 32) | (unsigned)__shfl((unsigned)at, leader);
+            if (redo) ta.redo[at + prefix_rank(m_redo)] = (uint32_t)(slot0 + lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef TILE_PROF
+    if (ta.prof && lane == 0)
+        for (int i = 0; i < TP_SLOTS; i++) atomicAdd(&ta.prof[i], pr[i]);
+}
+
+}  // namespace rtg

@@ -17,7 +17,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include "rt_gather.hip.h"
+#include "rt_gather_tile.hip.h"
 #include "rt_kernels.hip.h"
 #include "rt_queue.hip.h"
 
@@ -51,11 +51,13 @@ struct RenderCounters {
     rtq::Counts hits[MAX_LEVELS + 2];   // hits[d] = fill of the bounce queue of level d (1-based)
     rtq::Counts rays[MAX_LEVELS + 2];   // rays[d] = fill of the ray queue produced by shading level d
     rtq::Counts ray_draws[MAX_LEVELS + 2];   // chunks of rays[d] handed out to the tracing waves
-    rtq::Counts gather;                 // fill of the gather queue
+    rtq::Counts gather;                 // gather queue: [0] slots (windows of 64 per shading wave), [1] requests
     unsigned long long overflow_stack, overflow_queue;
     unsigned long long secondary_rays;
-    unsigned long long next_gather;     // draw counter of the gather kernel
-    unsigned long long pad[4];
+    unsigned long long next_gather;     // draw counter of the per-request gather kernel
+    unsigned long long next_window;     // draw counter of the group gather kernel
+    unsigned long long n_redo;          // requests the group kernel left to the per-request kernel
+    unsigned long long pad[2];
 };
 
 struct ShadeData {
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
         }
         rtq::push(rays, &ctr->rays[level], shard_cap, want[0], next[0], &ovf_queue);
         rtq::push(rays, &ctr->rays[level], shard_cap, want[1], next[1], &ovf_queue);
-        rtq::push(gq, &ctr->gather, shard_cap, want_g, g, &ovf_queue);
+        rtg::push_window(gq, &ctr->gather, shard_cap, want_g, g, &ovf_queue);
     }
     if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
 }

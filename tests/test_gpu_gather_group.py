@@ -1,0 +1,89 @@
+"""The grouped photon gather of the pixel path (64 neighbouring requests per wave, one per lane)
+against the per-request gather: same k-nearest sets, so the same estimates up to summation order."""
+import numpy as np
+import pytest
+
+import raytracer_amd as rt
+from conftest import build_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def water_photons(gpu_ctx):
+    s = build_scene(rt.Scene(), "water.obj", (0.26, 0.84, 1.0, 1.8), 1.33, (0, 0, 0))
+    s.emit_photons(60000, seed=7)
+    return s.photons_get(0)
+
+
+def _wall_queries(side, order="raster", seed=0):
+    """Points just inside the five visible walls with their normals, in raster order per wall."""
+    u, v = np.meshgrid(np.linspace(-0.97, 0.97, side), np.linspace(-0.97, 0.97, side), indexing="ij")
+    pos, nrm = [], []
+    for ax, val in [(1, -1.0), (1, 1.0), (2, -1.0), (2, 1.0), (0, -1.0)]:
+        p = np.zeros((side * side, 3)); n = np.zeros((side * side, 3))
+        others = [a for a in range(3) if a != ax]
+        p[:, others[0]] = u.ravel(); p[:, others[1]] = v.ravel(); p[:, ax] = val * 0.999
+        n[:, ax] = -val
+        pos.append(p); nrm.append(n)
+    pos, nrm = np.concatenate(pos), np.concatenate(nrm)
+    if order == "shuffled":
+        perm = np.random.default_rng(seed).permutation(len(pos))
+        pos, nrm = pos[perm], nrm[perm]
+    return pos, nrm
+
+
+def _compare(ctx, p, pos, nrm, what):
+    col = np.random.default_rng(3).uniform(0.2, 1.0, pos.shape)
+    want, _ = ctx.knn_estimate(p, pos, nrm, col)
+    got = ctx.knn_estimate_grouped(p, pos, nrm, col)
+    err = np.abs(got - want).max(axis=1)
+    # a request whose k-th and (k+1)-th distances are equal floats may keep the other photon
+    assert (err < 1e-9).mean() >= 0.999, (what, (err < 1e-9).mean())
+    assert err.max() < 2e-3, (what, err.max())
+    assert want.max() > 0.05      # the comparison is not about zeros
+
+
+@pytest.mark.parametrize("k", [1000, 100, 8])
+def test_grouped_gather_matches_the_per_request_gather(gpu_ctx, water_photons, k):
+    gpu_ctx.photons_upload(water_photons)
+    p = rt.default_params(photon_num=60000, photon_use=k)
+    pos, nrm = _wall_queries(40)
+    _compare(gpu_ctx, p, pos, nrm, f"raster k={k}")
+    _compare(gpu_ctx, p, pos[:1000 + 37], nrm[:1000 + 37], f"ragged last group k={k}")
+
+
+def test_incoherent_groups_fall_back(gpu_ctx, water_photons):
+    """Requests in random order: a group's box spans the room, the lists overflow or the bins crowd,
+    and the requests go to the per-request kernel; the answers must not change."""
+    gpu_ctx.photons_upload(water_photons)
+    pos, nrm = _wall_queries(24, "shuffled")
+    for k in (1000, 50):
+        _compare(gpu_ctx, rt.default_params(photon_num=60000, photon_use=k), pos, nrm, f"shuffled k={k}")
+
+
+def test_sparse_and_empty_maps(gpu_ctx, water_photons):
+    pos, nrm = _wall_queries(16)
+    p = rt.default_params(photon_num=60000, photon_use=1000)
+    gpu_ctx.photons_upload(water_photons[:700])          # fewer than k photons anywhere: every set is "all within the radius"
+    col = np.full(pos.shape, 0.8)
+    want, cnt = gpu_ctx.knn_estimate(p, pos, nrm, col)
+    got = gpu_ctx.knn_estimate_grouped(p, pos, nrm, col)
+    assert cnt.max() < 1000 and cnt.max() > 0
+    assert np.abs(got - want).max() < 1e-9
+    gpu_ctx.photons_upload(water_photons[:0])
+    assert np.array_equal(gpu_ctx.knn_estimate_grouped(p, pos, nrm, col), np.zeros_like(pos))
+
+
+def test_duplicate_photons(gpu_ctx, water_photons):
+    """Many photons at identical positions: equal distances crowd one bin, which the group form hands over."""
+    ph = np.concatenate([water_photons[:3000]] * 40)
+    gpu_ctx.photons_upload(ph)
+    pos, nrm = _wall_queries(12)
+    p = rt.default_params(photon_num=60000, photon_use=500)
+    col = np.full(pos.shape, 0.8)
+    want, _ = gpu_ctx.knn_estimate(p, pos, nrm, col)
+    got = gpu_ctx.knn_estimate_grouped(p, pos, nrm, col)
+    # with 40-fold duplicates the k-th distance is shared by many photons of different power: which of them
+    # belong to the set is arbitrary in both forms, so only the bulk of the estimate agrees
+    assert np.abs(got - want).max() < 0.05 * max(want.max(), 1e-9)

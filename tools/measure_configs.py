@@ -70,12 +70,15 @@ def main():
             (ns, nv), est = ctx.emit_photon_maps(nemit, seed=12345)
             t1 = time.perf_counter()
         print(f"C4 emission + ordering + kd-trees on the device: {ns} photons, kernels {est.kernel_ms:.2f} ms (emission {est.trace_kernel_ms:.2f}), wall {(t1 - t0) * 1e3:.1f} ms")
-        for k in (1000, 100):
-            p = rt.default_params(width=1920, height=1080, photon_num=nemit, photon_use=k)
-            st, dt = timed_render(ctx, p, reps=2)
-            rays = st.primary_rays + st.secondary_rays
-            print(f"C4 water 1920x1080 k={k}: {rays} rays, {st.gather_queries} gathers, device {st.kernel_ms:.2f} ms "
-                  f"(trace+shade {st.trace_kernel_ms:.2f} ms) -> {st.gather_queries / max(st.kernel_ms - st.trace_kernel_ms, 1e-9) / 1e3:.2f} Mqueries/s, host wall {dt*1e3:.0f} ms")
+        for mode in ("group", "query"):
+            os.environ["RT_GATHER_MODE"] = mode
+            for k in [int(x) for x in os.environ.get("C4_K", "1000,100").split(",")]:
+                p = rt.default_params(width=1920, height=1080, photon_num=nemit, photon_use=k)
+                st, dt = timed_render(ctx, p, reps=2)
+                rays = st.primary_rays + st.secondary_rays
+                print(f"C4 water 1920x1080 k={k} gather={mode}: {rays} rays, {st.gather_queries} gathers ({st.gather_single} one per wave), device {st.kernel_ms:.2f} ms "
+                      f"(trace+shade {st.trace_kernel_ms:.2f} ms) -> {st.gather_queries / max(st.kernel_ms - st.trace_kernel_ms, 1e-9) / 1e3:.2f} Mqueries/s, host wall {dt*1e3:.0f} ms")
+        os.environ.pop("RT_GATHER_MODE")
     if "c5" in which:
         n_inst = int(os.environ.get("C5_INST", "10000"))
         side = int(np.ceil(np.sqrt(n_inst)))
