@@ -1321,6 +1321,7 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     // row chunks bound the queue memory: at most ~4M distinct camera rays per chunk
     const long long max_samples = 4ll << 20;
     int chunk_rows = (int)std::max<long long>(8, (max_samples / ((long long)p->width * p->aadepth)) / 8 * 8);
+    if ((long long)p->width * chunk_rows >= (1ll << 25)) return fail(RT_ERR_LIMIT, "width %d: a block of 8 rows exceeds 2^25 pixels", p->width);
     std::vector<rtr::RenderCounters> hc((size_t)((row_end - row_begin + chunk_rows - 1) / chunk_rows));
     rt_stats total;
     memset(&total, 0, sizeof total);

@@ -47,6 +47,30 @@ struct RayRec {
 };
 constexpr uint32_t RAY_REFRACT = 0x80000000u;
 
+// The hit queues are filled in windows of 64 slots, one per producing wave (an 8x8 pixel tile, or the
+// hits of 64 queued rays), so that a consuming wave works on hit points that lie together; the
+// gather requests it queues then form one group.  The first record of a window carries the number of
+// hits in bits 25..31 of `pixel` (a pixel index stays below 2^25: a call handles at most ~4M camera rays).
+constexpr uint32_t HIT_PIXEL_MASK = (1u << 25) - 1u;
+__device__ __forceinline__ void push_hits(HitRec* q, rtq::Counts* cnt, unsigned long long shard_cap, bool want, HitRec& rec, unsigned long long* overflow)
+{
+    unsigned long long m = __ballot(want);
+    if (m == 0) return;
+    const unsigned shard = rtq::wave_index() & (rtq::SHARDS - 1);
+    const int leader = __builtin_ctzll(m);
+    unsigned long long base = 0;
+    if ((int)rtq::lane_id() == leader) {
+        base = atomicAdd(&cnt->n[shard][0], (unsigned long long)WAVE);
+        rec.pixel |= (uint32_t)__builtin_popcountll(m) << 25;
+    }
+    unsigned lo = __shfl((unsigned)base, leader), hi = __shfl((unsigned)(base >> 32), leader);
+    base = ((unsigned long long)hi << 32) | lo;
+    if (want) {
+        if (base + WAVE <= shard_cap) q[(unsigned long long)shard * shard_cap + base + rtq::prefix_rank(m)] = rec;
+        else *overflow = 1;
+    }
+}
+
 struct RenderCounters {
     rtq::Counts hits[MAX_LEVELS + 2];   // hits[d] = fill of the bounce queue of level d (1-based)
     rtq::Counts rays[MAX_LEVELS + 2];   // rays[d] = fill of the ray queue produced by shading level d
@@ -117,7 +141,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
                     want = true;
                 }
             }
-            rtq::push(hits, &ctr->hits[1], shard_cap, want, rec, &ovf_queue);
+            push_hits(hits, &ctr->hits[1], shard_cap, want, rec, &ovf_queue);
         }
     }
     if (ovf_stack) atomicMax(&ctr->overflow_stack, 1ull);
@@ -139,13 +163,15 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
         uint32_t first, n_shard;
         rtq::locate(map, chunk, WAVE, shard, first, n_shard);
         const uint32_t i = first + lane;
-        bool active = i < n_shard;
+        const uint32_t in_window = in[(unsigned long long)shard * shard_cap + first].pixel >> 25;
+        bool active = lane < (int)in_window;
         RayRec next[2];
         bool want[2] = {false, false};
         rtg::GatherRec g;
         bool want_g = false;
         if (active) {
             HitRec rec = in[(unsigned long long)shard * shard_cap + i];
+            rec.pixel &= HIT_PIXEL_MASK;
             rtm::D3 hit_dir = {rec.dir[0], rec.dir[1], rec.dir[2]};
             rtm::D3 hit_pos = rtm::vadd(rtm::D3{rec.pos[0], rec.pos[1], rec.pos[2]}, rtm::vmul(hit_dir, a.accuracy));   // main.cpp:162
             const rtf::ObjShade& obj = sd.objs[rec.obj];
@@ -266,7 +292,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
                 want = true;
             }
         }
-        rtq::push(out, &ctr->hits[level + 1], shard_cap, want, next, &ovf_queue);
+        push_hits(out, &ctr->hits[level + 1], shard_cap, want, next, &ovf_queue);
     }
     if (ovf_stack) atomicMax(&ctr->overflow_stack, 1ull);
     if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
