@@ -76,6 +76,8 @@ struct TileArgs {
 };
 enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_SLOTS };
 
+typedef float f2 __attribute__((ext_vector_type(2)));   // two photons per packed instruction
+
 __device__ __forceinline__ float bcast(float v, int src) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), src)); }
 
 __device__ __forceinline__ float wave_min_f(float v)
@@ -173,6 +175,17 @@ __device__ __attribute__((noinline)) int group_walk(PhotonMapView pm, float glx,
     return n_leaf | (n_piv << 16);
 }
 
+// squared distances from (qx, qy, qz) to photons j and j + 1 of a step (held by lanes j, j + 1 of p); the
+// operation order per photon is that of the per-request kernel, so the values are the same floats
+__device__ __forceinline__ f2 pair_d2(const float4& p, int j, float qx, float qy, float qz)
+{
+    const f2 xs = {bcast(p.x, j), bcast(p.x, j + 1)}, ys = {bcast(p.y, j), bcast(p.y, j + 1)}, zs = {bcast(p.z, j), bcast(p.z, j + 1)};
+    const f2 dx = f2{qx, qx} - xs, dy = f2{qy, qy} - ys, dz = f2{qz, qz} - zs;
+    return dx * dx + dy * dy + dz * dz;
+}
+__device__ __forceinline__ f2 shell_pos(f2 d2, float lower, float scale) { return (d2 - f2{lower, lower}) * f2{scale, scale} + f2{1.f, 1.f}; }
+__device__ __forceinline__ int shell_bin_of(float pos) { return (int)__builtin_amdgcn_fmed3f(pos, 0.f, (float)(T_BINS - 1)); }
+
 // Histogram bin of a squared distance: bin 0 holds everything below `lower` (distances the triangle
 // inequality already puts inside the set), bins 1.. are linear over [lower, bound).  Monotone in d2.
 __device__ __forceinline__ int shell_bin(float d2, float lower, float scale)
@@ -240,11 +253,11 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
         const int n_now = __builtin_amdgcn_readfirstlane(n);
         for (int j0 = 0; j0 < n_now; j0 += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int j = j0 + u;
-                const float dx = qx - bcast(p_now.x, j), dy = qy - bcast(p_now.y, j), dz = qz - bcast(p_now.z, j);
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                atomicAdd(d2 < lim ? mine + shell_bin(d2, lower, scale) * WAVE : sink, 1u);
+            for (int u = 0; u < 8; u += 2) {
+                const f2 d2 = pair_d2(p_now, j0 + u, qx, qy, qz);
+                const f2 at = shell_pos(d2, lower, scale);
+                atomicAdd(d2.x < lim ? mine + shell_bin_of(at.x) * WAVE : sink, 1u);
+                atomicAdd(d2.y < lim ? mine + shell_bin_of(at.y) * WAVE : sink, 1u);
             }
         }
     }
@@ -269,16 +282,13 @@ __device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ po
         const int n_now = __builtin_amdgcn_readfirstlane(n);
         for (int j0 = 0; j0 < n_now; j0 += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int j = j0 + u;
-                const float dx = qx - bcast(p_now.x, j), dy = qy - bcast(p_now.y, j), dz = qz - bcast(p_now.z, j);
-                const float d2 = dx * dx + dy * dy + dz * dz;
-                const bool hit = d2 < lim && shell_bin(d2, lower, scale) == crit;
-                if (__ballot(hit)) {           // rare: a few dozen photons per request
-                    if (hit && cnt < T_CRIT) {
-                        cell[cnt * WAVE + lane] = __float_as_uint(d2);
-                        cnt++;
-                    }
+            for (int u = 0; u < 8; u += 2) {
+                const f2 d2 = pair_d2(p_now, j0 + u, qx, qy, qz);
+                const f2 at = shell_pos(d2, lower, scale);
+                const bool hit0 = d2.x < lim && shell_bin_of(at.x) == crit, hit1 = d2.y < lim && shell_bin_of(at.y) == crit;
+                if (__ballot(hit0 || hit1)) {           // rare: a few dozen photons per request
+                    if (hit0 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d2.x); cnt++; }
+                    if (hit1 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d2.y); cnt++; }
                 }
             }
         }
@@ -321,11 +331,11 @@ __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ po
         }
         const int n_now = __builtin_amdgcn_readfirstlane(n);
         for (int j0 = 0; j0 < n_now; j0 += 4) {
+            const f2 d2a = pair_d2(p_now, j0, qx, qy, qz), d2b = pair_d2(p_now, j0 + 2, qx, qy, qz);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int j = j0 + u;
-                const float dx = qx - bcast(p_now.x, j), dy = qy - bcast(p_now.y, j), dz = qz - bcast(p_now.z, j);
-                const float d2 = dx * dx + dy * dy + dz * dz;
+                const float d2 = u == 0 ? d2a.x : (u == 1 ? d2a.y : (u == 2 ? d2b.x : d2b.y));
                 bool in = d2 < lim;
                 if (d2 == lim) { in = eq_seen < want_eq; eq_seen++; }
                 if (__ballot(in)) {
@@ -483,6 +493,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 int rank[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) { e[u] = cell[(i0 + u < T_CRIT ? i0 + u : T_CRIT - 1) * WAVE + lane]; rank[u] = 0; }
+#pragma unroll 4
                 for (int j = 0; j < max_cnt; j++) {
                     const uint32_t o = cell[j * WAVE + lane];
                     const bool mine = j < cnt;
