@@ -387,7 +387,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         // silhouette, two producers' requests in one window): each round takes the requests close to one of
         // those still waiting; what is left after ROUNDS rounds, and rounds of only a few requests, go to the
         // per-request kernel.
-        constexpr int ROUNDS = 4, MIN_LANES = 12;
+        // (a round costs about as much as 20 requests answered singly at k = 1000, as 8 at k = 100)
+        constexpr int ROUNDS = 4;
+        const int MIN_LANES = gp.k >= 400 ? 20 : 10;
         for (int round = 0; round < ROUNDS; round++) {
             const unsigned long long m_todo = __ballot(todo);
             if (!m_todo) break;
