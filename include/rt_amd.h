@@ -76,6 +76,14 @@ typedef struct rt_render_params {
     double accuracy;          /* main.cpp:614                                                    */
     double photon_dist;       /* PHOTONDIST, Kdtree.cpp:6                                        */
     double light_pos[3];      /* main.cpp:654                                                    */
+    /* Depth of field, main.cpp:35-37, 792-810: dof_samples rays per sample through a jittered lens position
+     * toward the focal point (1 = off, the reference's setting).  Glossy materials (special = x.xx7654,
+     * main.cpp:177) take 16 jittered reflection / refraction rays whatever these fields say.  Every draw
+     * is a function of (pixel or hit point, draw number, rng_seed), not of a shared generator. */
+    double focal_len;         /* FOCAL_LEN 2.6                                                   */
+    double aperture;          /* APERTURE_SIZE 0.2                                               */
+    int32_t dof_samples;      /* DOF_SAMPLE 1                                                    */
+    uint32_t rng_seed;
 } rt_render_params;
 
 /* Ray counters of one call (the Mrays/s metric counts closest-hit queries, i.e. BVH::Shoot calls). */

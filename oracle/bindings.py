@@ -40,6 +40,7 @@ class Params(ctypes.Structure):
     _fields_ = [
         ("photon_num", c_i), ("photon_use", c_i), ("tracing_depth", c_i), ("bounce", c_i),
         ("head_quirk", c_i), ("use_photon_map", c_i), ("accuracy", c_d), ("photon_dist", c_d),
+        ("focal_len", c_d), ("aperture", c_d), ("dof_samples", c_i), ("counter_rng", c_i), ("rng_seed", ctypes.c_uint32), ("pad_", c_i),
     ]
 
 

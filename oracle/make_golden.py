@@ -287,6 +287,43 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "render_sss_64.npz"), rgb=rgb.reshape(h, w, 3), photons=surf, volume_photons=vol,
                         rgbs=np.array(sss), ior=1.3)
 
+    # ---------------------------------------------------------------- G9: glossy materials (main.cpp:139-156, 177-257)
+    # special = x.xx7654 switches getColorAt to 16 jittered reflection / refraction rays.  At HEAD the
+    # recursion shades the old object again, so the glossy objects themselves come out black whatever the
+    # draws; what the draws do change is the state of the shared generator, which the subsurface march of
+    # the teapot hits shaded afterwards reads.  Equal colours therefore pin the number and order of draws of
+    # the glossy loops (including total internal reflection and the in-loop normal flip).
+    ref = Reference(); orc = Oracle()
+    for api in (ref, orc):
+        api.load_obj(os.path.join(DATA, "teapot_normal.obj"), sss, 1.3, (0, -0.7, 0))
+        api.add_sphere((0.0, 0.35, 0.55), 0.3, (1.0, 1.0, 1.0, 0.987654), 1.0)       # reflectWhite of the GLOSSY build (main.cpp:640)
+        api.add_sphere((0.0, 0.35, -0.55), 0.3, (1.0, 1.0, 1.0, 1.887654), 1.5)      # refractWhite of the GLOSSY build (main.cpp:641)
+        api.add_cornell()
+        api.build_bvh()
+        api.seed(4242)
+    nr = ref.emit_photons(10000); no = orc.emit_photons(10000)
+    check(f"photon count glossy scene ({nr})", nr, no)
+    surf, vol = ref.photons_get(0)[:, :9].copy(), ref.photons_get(1)[:, :9].copy()
+    ref.build_kdtree(); orc.build_kdtree()
+    w = h = 64
+    org, d = ref.primary_rays(w, h, CAM)
+    ids, t = ref.shoot(org, d)
+    hit = np.flatnonzero((ids >= 0) & (t > 1e-6))
+    # the batch: some hits on each ball first, subsurface hits after them
+    mirror, glass, teapot = hit[ids[hit] == 992], hit[ids[hit] == 993], hit[ids[hit] < 992]
+    sel = np.concatenate([mirror[::6], glass[::6], teapot[::2]])
+    print(f"   {len(mirror[::6])} + {len(glass[::6])} hits on the glossy balls, then {len(teapot[::2])} on the subsurface teapot")
+    pos = org[sel] + d[sel] * t[sel][:, None]
+    ref.seed(99); orc.seed(99)
+    orc.params.head_quirk = 1
+    rcol = ref.get_color_at(pos, d[sel], ids[sel], 1); ocol = orc.get_color_at(pos, d[sel], ids[sel], 1)
+    check("getColorAt with glossy balls before subsurface hits (same RNG sequence)", rcol, ocol)
+    ref.seed(100)
+    other = ref.get_color_at(pos, d[sel], ids[sel], 1)
+    check("... and the draws matter (another seed changes the subsurface colours)", bool(np.array_equal(other, rcol)), False)
+    np.savez_compressed(os.path.join(GOLD, "glossy_head_64.npz"), pos=pos, dir=d[sel], ids=ids[sel].astype(np.int32), rgb=rcol,
+                        photons=surf, volume_photons=vol)
+
     print()
     if failures:
         print("FAILED:", failures)

@@ -514,8 +514,37 @@ struct ShadeCtx {
     const orc_scene* s;
     const orc_params* p;
     int64_t rays = 0;
-    std::mt19937* gen = nullptr;  // eye-path RNG of the SSS march (main.cpp:374)
+    std::mt19937* gen = nullptr;  // eye-path RNG: glossy rays (main.cpp:140-141), SSS march (main.cpp:374), lens jitter (main.cpp:803-804)
 };
+
+// counter_rng = 1: uniform in (0, 1) as a function of two counters and the seed
+double counter_uniform(uint32_t a, uint32_t b, uint32_t seed)
+{
+    uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ seed * 0xC2B2AE3Du;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return ((double)x + 0.5) * (1.0 / 4294967296.0);
+}
+uint32_t fbits(double v)
+{
+    float f = (float)v;
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+uint32_t path_key(const V3& p) { return fbits(p.x) * 0x9E3779B1u ^ fbits(p.y) * 0x85EBCA77u ^ fbits(p.z) * 0xC2B2AE3Du; }
+
+// computeGlossyRay, main.cpp:139-156; a, b are its two draws in call order
+V3 glossy_ray(const V3& reflection_direction, const V3& normal, double glossiness, double a, double b)
+{
+    double theta = std::acos(std::pow(1 - a, glossiness));
+    double phi = 2 * PI_REF * b;
+    double x = std::sin(theta) * std::cos(phi);
+    double z = std::sin(theta) * std::sin(phi);
+    V3 u = vcross(reflection_direction, normal);
+    V3 v = vcross(reflection_direction, u);
+    return vnorm(vadd(vmul(u, x), vadd(vmul(v, z), reflection_direction)));
+}
+const int GLOSSY_SAMPLE = 16;   // main.cpp:32
 
 Col color_at(ShadeCtx& cx, V3 hit_pos, const V3& hit_dir, int hit_obj, int depth)
 {
@@ -533,47 +562,76 @@ Col color_at(ShadeCtx& cx, V3 hit_pos, const V3& hit_dir, int hit_obj, int depth
     if (colorSpecial > 0) {
         V3 R = reflect_dir(hit_normal, hit_dir);
         Col acc(0, 0, 0, 0);
-        {
+        // main.cpp:177-179: a material whose special * 100 ends in .7654 takes GLOSSY_SAMPLE jittered rays
+        double frac = colorSpecial * 100.0 - std::floor(colorSpecial * 100.0);
+        int sample = (frac - 0.7654 < 0.0001 && frac - 0.7653 > 0) ? GLOSSY_SAMPLE : 1;
+        std::uniform_real_distribution<> dis_rand(0, 1);
+        const uint32_t key = path_key(hit_pos);
+        for (int i = 0; i < sample; i++) {
+            V3 dir = R;
+            if (sample != 1) {
+                double a, b;
+                if (P.counter_rng) {
+                    uint32_t draw = (uint32_t)(depth * 1024 + i * 2);
+                    a = counter_uniform(key, draw, P.rng_seed); b = counter_uniform(key, draw + 1u, P.rng_seed);
+                } else {
+                    a = dis_rand(*cx.gen); b = dis_rand(*cx.gen);
+                }
+                dir = glossy_ray(R, hit_normal, 0.2, a, b);
+            }
             double dist = 1e9;
-            int io = shoot(s, hit_pos, R, dist);
+            int io = shoot(s, hit_pos, dir, dist);
             cx.rays++;
             bool go = P.head_quirk ? (dist > accuracy) : (io >= 0 && dist > accuracy);
             if (go) {
-                V3 npos = vadd(hit_pos, vmul(R, dist));
+                V3 npos = vadd(hit_pos, vmul(R, dist));                       // main.cpp:195: along the un-jittered direction
                 Col rc = color_at(cx, npos, R, P.head_quirk ? hit_obj : io, depth + 1);
                 if (colorSpecial > 1) acc = cadd(acc, cscale(rc, 2 - hit_color.s));
                 else acc = cadd(acc, rc);
             }
         }
-        acc = cscale(acc, 1.0 / 1);
+        acc = cscale(acc, 1.0 / sample);
         final_color = cadd(final_color, acc);
         if (colorSpecial > 1) {
             Col racc(0, 0, 0, 0);
-            double refractance = hit_color.s - 1;
-            double n1n2 = 1.0 / obj.ior;
-            double dot1 = vdot(hit_normal, vneg(hit_dir));
-            if (dot1 < 0) {
-                hit_normal = vneg(hit_normal);
-                dot1 = vdot(hit_normal, vneg(hit_dir));
-                n1n2 = 1.0 / n1n2;
-            }
-            double nNL = n1n2 * dot1;
-            double underSQRT = 1 - n1n2 * n1n2 * (1 - dot1 * dot1);
-            if (underSQRT > 0) {
-                double coeffN = nNL - std::sqrt(underSQRT);
-                V3 T = vadd(vmul(hit_normal, coeffN), vneg(vmul(vneg(hit_dir), n1n2)));
-                double dist = 1e9;
-                int io = shoot(s, hit_pos, T, dist);
-                cx.rays++;
-                bool go = P.head_quirk ? (dist > accuracy) : (io >= 0 && dist > accuracy);
-                if (go) {
-                    V3 npos = vadd(hit_pos, vmul(T, accuracy + dist));
-                    Col rc = color_at(cx, npos, T, P.head_quirk ? hit_obj : io, depth + 1);
-                    racc = cadd(racc, cscale(rc, refractance));
+            for (int i = 0; i < sample; i++) {
+                double refractance = hit_color.s - 1;
+                double n1n2 = 1.0 / obj.ior;
+                double dot1 = vdot(hit_normal, vneg(hit_dir));
+                if (dot1 < 0) {                                                 // (flips the normal for the later passes, too)
+                    hit_normal = vneg(hit_normal);
+                    dot1 = vdot(hit_normal, vneg(hit_dir));
+                    n1n2 = 1.0 / n1n2;
                 }
+                double nNL = n1n2 * dot1;
+                double underSQRT = 1 - n1n2 * n1n2 * (1 - dot1 * dot1);
+                if (underSQRT > 0) {
+                    double coeffN = nNL - std::sqrt(underSQRT);
+                    V3 T = vadd(vmul(hit_normal, coeffN), vneg(vmul(vneg(hit_dir), n1n2)));
+                    V3 dir = T;
+                    if (sample != 1) {
+                        double a, b;
+                        if (P.counter_rng) {
+                            uint32_t draw = (uint32_t)(depth * 1024 + 512 + i * 2);
+                            a = counter_uniform(key, draw, P.rng_seed); b = counter_uniform(key, draw + 1u, P.rng_seed);
+                        } else {
+                            a = dis_rand(*cx.gen); b = dis_rand(*cx.gen);
+                        }
+                        dir = glossy_ray(T, hit_normal, 0.2, a, b);
+                    }
+                    double dist = 1e9;
+                    int io = shoot(s, hit_pos, dir, dist);
+                    cx.rays++;
+                    bool go = P.head_quirk ? (dist > accuracy) : (io >= 0 && dist > accuracy);
+                    if (go) {
+                        V3 npos = vadd(hit_pos, vmul(T, accuracy + dist));
+                        Col rc = color_at(cx, npos, T, P.head_quirk ? hit_obj : io, depth + 1);
+                        racc = cadd(racc, cscale(rc, refractance));
+                    }
+                }
+                racc = cscale(racc, 1.0 / sample);                              // main.cpp:255-256: inside the loop
+                final_color = cadd(final_color, racc);
             }
-            racc = cscale(racc, 1.0 / 1);
-            final_color = cadd(final_color, racc);
         }
     } else if (colorSpecial <= 0) {
         Col sssColor(0, 0, 0, 0);
@@ -833,6 +891,12 @@ void orc_default_params(orc_params* p)
     p->tracing_depth = 4;
     p->bounce = 5;
     p->head_quirk = 0;
+    p->focal_len = 2.6;
+    p->aperture = 0.2;
+    p->dof_samples = 1;
+    p->counter_rng = 0;
+    p->rng_seed = 12345u;
+    p->pad_ = 0;
     p->use_photon_map = 1;
     p->accuracy = 0.000001;
     p->photon_dist = 0.28;
@@ -1411,14 +1475,37 @@ void orc_render(const orc_scene* s, const orc_params* P, int32_t w, int32_t h, i
                             int aa_index = aay * aadepth + aax;
                             V3 d = cam_ray_dir(c, w, h, aadepth, x, y, aax);
                             double dof[3] = {0, 0, 0};
-                            double dist = 1e9;
-                            int io = shoot(s, c.pos, d, dist);
-                            cx.rays++;
-                            if (io >= 0 && dist > P->accuracy) {
-                                V3 ipos = vadd(c.pos, vmul(d, dist));
-                                Col col = color_at(cx, ipos, d, io, 1);
-                                dof[0] += col.r; dof[1] += col.g; dof[2] += col.b;
+                            const int n_dof = P->dof_samples > 1 ? P->dof_samples : 1;
+                            // main.cpp:792-826
+                            V3 focal = vadd(c.pos, vmul(d, P->focal_len));
+                            V3 worldUp(0, 1, 0);
+                            V3 camUp = vadd(worldUp, vneg(vmul(d, vdot(worldUp, d))));
+                            V3 camSide = vcross(camUp, d);
+                            std::uniform_real_distribution<> dis_rand_dof(-P->aperture, P->aperture);
+                            for (int ds = 0; ds < n_dof; ds++) {
+                                V3 org = c.pos, dj = d;
+                                if (n_dof != 1) {
+                                    double jx, jy;
+                                    if (P->counter_rng) {
+                                        uint32_t px = (uint32_t)((long long)y * w + x), draw = (uint32_t)(((aay * aadepth + aax) * n_dof + ds) * 2);
+                                        jx = -P->aperture + 2 * P->aperture * counter_uniform(px, draw, P->rng_seed);
+                                        jy = -P->aperture + 2 * P->aperture * counter_uniform(px, draw + 1u, P->rng_seed);
+                                    } else {
+                                        jx = dis_rand_dof(g); jy = dis_rand_dof(g);
+                                    }
+                                    org = vadd(vadd(c.pos, vmul(camUp, jx)), vmul(camSide, jy));
+                                    dj = vnorm(vadd(focal, vneg(org)));
+                                }
+                                double dist = 1e9;
+                                int io = shoot(s, org, dj, dist);
+                                cx.rays++;
+                                if (io >= 0 && dist > P->accuracy) {
+                                    V3 ipos = vadd(org, vmul(d, dist));          // main.cpp:821: the un-jittered direction
+                                    Col col = color_at(cx, ipos, d, io, 1);
+                                    dof[0] += col.r; dof[1] += col.g; dof[2] += col.b;
+                                }
                             }
+                            dof[0] /= n_dof; dof[1] /= n_dof; dof[2] /= n_dof;
                             tr[aa_index] = dof[0] / 1; tg[aa_index] = dof[1] / 1; tb[aa_index] = dof[2] / 1;
                         }
                     double R = 0, G = 0, B = 0;

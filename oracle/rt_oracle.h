@@ -29,6 +29,14 @@ typedef struct orc_params {
     int32_t use_photon_map;  /* 0: diffuse hits return black without a gather (no photon map loaded) */
     double accuracy;         /* 1e-6 (main.cpp:614) */
     double photon_dist;      /* PHOTONDIST 0.28 (Kdtree.cpp:6) */
+    double focal_len;        /* FOCAL_LEN 2.6 (main.cpp:36) */
+    double aperture;         /* APERTURE_SIZE 0.2 (main.cpp:37) */
+    int32_t dof_samples;     /* DOF_SAMPLE 1 (main.cpp:35) */
+    int32_t counter_rng;     /* 0: draws come from the scene's std::mt19937 in call order, as in the reference;
+                                1: every draw is a function of (pixel or hit point, draw number, rng_seed) -- the
+                                form a parallel renderer can reproduce */
+    uint32_t rng_seed;
+    int32_t pad_;
 } orc_params;
 
 void orc_default_params(orc_params* p);

@@ -32,6 +32,7 @@ class RenderParams(ctypes.Structure):
         ("struct_size", ctypes.c_uint32), ("width", c_i32), ("height", c_i32), ("aadepth", c_i32), ("tracing_depth", c_i32),
         ("photon_num", c_i32), ("photon_use", c_i32), ("head_quirk", c_i32), ("use_photon_map", c_i32), ("precision", c_i32),
         ("shadow_rays", c_i32), ("count_work", c_i32), ("band_rows", c_i32), ("n_parts", c_i32), ("part", c_i32), ("accuracy", c_d), ("photon_dist", c_d), ("light_pos", c_d * 3),
+        ("focal_len", c_d), ("aperture", c_d), ("dof_samples", c_i32), ("rng_seed", ctypes.c_uint32),
     ]
 
 

@@ -91,6 +91,7 @@ struct rt_context {
     int n_nodes = 0;
     int n_objects = 0;
     bool has_scene = false;
+    bool has_glossy = false;  // some material takes the 16-sample loops of main.cpp:177-257
     DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
     // photon maps in HBM (0 surface, 1 volume)
     DevBuf ph_pos[2], ph_aux[2], ph_axis[2], ph_order[2], ph_box[2];
@@ -308,6 +309,10 @@ void rt_default_params(rt_render_params* p)
     p->shadow_rays = 0;
     p->accuracy = 0.000001;             // main.cpp:614
     p->photon_dist = 0.28;              // Kdtree.cpp:6
+    p->focal_len = 2.6;                 // main.cpp:36
+    p->aperture = 0.2;                  // main.cpp:37
+    p->dof_samples = 1;                 // main.cpp:35
+    p->rng_seed = 12345u;
     p->light_pos[0] = 0.1; p->light_pos[1] = 0.2; p->light_pos[2] = 0;   // main.cpp:654
 }
 
@@ -725,7 +730,11 @@ int upload_shading(rt_context* ctx, const rth::Scene& s)
 {
     int rc;
     std::vector<rtf::ObjShade> sh(s.objects.size());
-    for (size_t i = 0; i < sh.size(); i++) sh[i] = s.objects[i].sh;
+    ctx->has_glossy = false;
+    for (size_t i = 0; i < sh.size(); i++) {
+        sh[i] = s.objects[i].sh;
+        if (rtm::glossy_special(sh[i].color[3])) ctx->has_glossy = true;
+    }
     if ((rc = upload(ctx->objs, sh, ctx->stream))) return rc;
     std::vector<rtf::TexDesc> td;
     std::vector<double> pool;
@@ -1245,11 +1254,12 @@ template <class R>
 int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, double* d_acc, rtr::RenderCounters* host_ctr)
 {
     const int rows = a.row_end - a.row_begin;
-    const unsigned long long samples = (unsigned long long)a.width * rows * a.aadepth;
+    const unsigned long long samples = (unsigned long long)a.width * rows * (a.dof_samples > 1 ? a.aadepth * a.aadepth * a.dof_samples : a.aadepth);
     const int levels = std::min(p->tracing_depth, rtr::MAX_LEVELS);
     // worst case: every hit of a level spawns two (reflection + refraction); the queues are split into
     // shards of equal capacity that fill nearly evenly (producers pick shards round-robin), with slack
-    const unsigned long long cap_hits = samples << std::max(0, std::min(levels - 1, 3));
+    // (a glossy hit spawns 16 + 16 rays: such scenes are rendered in small row blocks with room for two glossy bounces in a row)
+    const unsigned long long cap_hits = samples << (ctx->has_glossy && levels > 1 ? 10 : std::max(0, std::min(levels - 1, 3)));
     // (a multiple of 64: the gather queue is filled in whole windows of 64 slots)
     const unsigned long long shard_cap = (((cap_hits + rtq::SHARDS - 1) / rtq::SHARDS + 16384) + 63) & ~63ull;
     const unsigned long long cap_total = shard_cap * rtq::SHARDS;
@@ -1284,7 +1294,7 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
         gp.r2 = (float)(p->photon_dist * p->photon_dist);
         gp.norm = (double)(p->photon_num / 16) * 3.1415926;
         gp.photon_num = (double)p->photon_num;
-        gp.seed = 12345u;
+        gp.seed = p->rng_seed;
         if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, shard_cap, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp, d_acc)))
             return rc;
     }
@@ -1306,6 +1316,7 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     int part_rows = p->band_rows > 0 ? p->height / p->n_parts : p->height;
     if (row_begin < 0 || row_end > part_rows || row_begin >= row_end) return fail(RT_ERR_INVALID, "rows [%d,%d) outside [0,%d)", row_begin, row_end, part_rows);
     if (p->aadepth < 1 || p->aadepth > 16) return fail(RT_ERR_INVALID, "aadepth %d", p->aadepth);
+    if (p->dof_samples < 1 || p->dof_samples > 4096) return fail(RT_ERR_INVALID, "dof_samples %d outside [1,4096]", p->dof_samples);
     if (p->tracing_depth < 1 || p->tracing_depth > rtr::MAX_LEVELS) return fail(RT_ERR_INVALID, "tracing_depth %d outside [1,%d]", p->tracing_depth, rtr::MAX_LEVELS);
     if (p->use_photon_map && (p->photon_use < 1 || p->photon_use > rtg::MAX_K)) return fail(RT_ERR_LIMIT, "photon_use %d outside [1,%d]", p->photon_use, rtg::MAX_K);
     if ((rc = use_device(ctx))) return rc;
@@ -1317,10 +1328,13 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     a.aadepth = p->aadepth;
     a.accuracy = p->accuracy;
     a.head_quirk = p->head_quirk; a.use_photon_map = p->use_photon_map;
+    a.seed = p->rng_seed;
+    a.dof_samples = p->dof_samples; a.focal_len = p->focal_len; a.aperture = p->aperture;
 
     // row chunks bound the queue memory: at most ~4M distinct camera rays per chunk
-    const long long max_samples = 4ll << 20;
-    int chunk_rows = (int)std::max<long long>(8, (max_samples / ((long long)p->width * p->aadepth)) / 8 * 8);
+    const long long max_samples = ctx->has_glossy ? 32ll << 10 : 4ll << 20;
+    const long long per_pixel = p->dof_samples > 1 ? (long long)p->aadepth * p->aadepth * p->dof_samples : p->aadepth;
+    int chunk_rows = (int)std::max<long long>(8, (max_samples / ((long long)p->width * per_pixel)) / 8 * 8);
     if ((long long)p->width * chunk_rows >= (1ll << 25)) return fail(RT_ERR_LIMIT, "width %d: a block of 8 rows exceeds 2^25 pixels", p->width);
     std::vector<rtr::RenderCounters> hc((size_t)((row_end - row_begin + chunk_rows - 1) / chunk_rows));
     rt_stats total;
@@ -1345,7 +1359,7 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
         hipLaunchKernelGGL(rtr::resolve_kernel, dim3((unsigned)((npx + threads - 1) / threads)), dim3(threads), 0, ctx->stream, (long long)npx, p->aadepth,
                            acc, d_rgb ? acc : nullptr, d_bgr8 ? d_bgr8 + off * 3 : nullptr);
         HIP_TRY(hipGetLastError());
-        total.primary_rays += (uint64_t)npx * p->aadepth;
+        total.primary_rays += (uint64_t)npx * (uint64_t)per_pixel;
     }
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (stats) {

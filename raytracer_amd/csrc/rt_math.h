@@ -323,6 +323,44 @@ RT_HD void obj_color(const rtf::ObjShade& p, const rtf::TexDesc* maps, const dou
     out[0] = p.color[0]; out[1] = p.color[1]; out[2] = p.color[2]; out[3] = p.color[3];
 }
 
+// ---- sampling extras of the shade loop (main.cpp:139-156 glossy rays, :792-810 lens jitter).  The
+// reference draws from one std::mt19937 shared by all threads; here every draw is a pure function of
+// (where on the path, which draw, seed), so a frame does not depend on scheduling.
+RT_HD double counter_uniform(uint32_t a, uint32_t b, uint32_t seed)     // uniform in (0, 1)
+{
+    uint32_t x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ seed * 0xC2B2AE3Du;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return ((double)x + 0.5) * (1.0 / 4294967296.0);
+}
+RT_HD uint32_t float_bits(float f)
+{
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    return u;
+}
+// identifies a point of a path whatever the order in which paths are processed
+RT_HD uint32_t path_key(D3 p) { return float_bits((float)p.x) * 0x9E3779B1u ^ float_bits((float)p.y) * 0x85EBCA77u ^ float_bits((float)p.z) * 0xC2B2AE3Du; }
+
+// the material switch of main.cpp:177: special * 100 has the fractional part .7654
+RT_HD bool glossy_special(double special)
+{
+    double f = special * 100.0 - floor(special * 100.0);
+    return f - 0.7654 < 0.0001 && f - 0.7653 > 0;
+}
+constexpr int GLOSSY_SAMPLE = 16;      // main.cpp:32
+
+// computeGlossyRay, main.cpp:139-156 (a, b: the two uniform draws)
+RT_HD D3 glossy_ray(D3 reflection_direction, D3 normal, double glossiness, double a, double b)
+{
+    double theta = acos(pow(1 - a, glossiness));
+    double phi = 2 * 3.1415926 * b;
+    double x = sin(theta) * cos(phi);
+    double z = sin(theta) * sin(phi);
+    D3 u = vcross(reflection_direction, normal);
+    D3 v = vcross(reflection_direction, u);
+    return vnorm(vadd(vmul(u, x), vadd(vmul(v, z), reflection_direction)));
+}
+
 // computeReflectionDir, main.cpp:125-136
 RT_HD D3 reflect_dir(D3 normal, D3 ray_in)
 {

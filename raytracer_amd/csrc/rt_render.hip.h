@@ -40,7 +40,8 @@ struct HitRec {
 // a secondary ray waiting to be traced
 struct RayRec {
     double org[3];      // hit_pos of the surface it leaves (main.cpp:162)
-    double dir[3];
+    double dir[3];      // direction Shoot is called with (a glossy sample's jittered direction, main.cpp:183-188)
+    double cont[3];     // direction the path goes on with: the un-jittered one (main.cpp:195-196, 246-247)
     double weight;      // throughput of the path once this ray is followed
     uint32_t pixel;     // bit 31: refraction ray (child position uses accuracy + t, main.cpp:246)
     int32_t obj;        // object the ray leaves (HEAD recursion shades it again, main.cpp:198,249)
@@ -97,7 +98,16 @@ struct RenderArgs {
     int aadepth;
     double accuracy;
     int head_quirk, use_photon_map;
+    uint32_t seed;      // of the counter-based draws (glossy rays, lens jitter)
+    int dof_samples;    // main.cpp:35 (1: no depth of field)
+    double focal_len, aperture;
 };
+
+__device__ __forceinline__ int rtk_wave_max(int v)
+{
+    for (int off = 32; off > 0; off >>= 1) { int o = __shfl_xor(v, off); v = o > v ? o : v; }
+    return v;
+}
 
 template <class R, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits,
@@ -121,28 +131,46 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
         int yc = a.row_begin + yl;
         int y = a.band_rows > 0 ? ((yc / a.band_rows) * a.n_parts + a.part) * a.band_rows + yc % a.band_rows : yc;
         // The reference shoots aadepth^2 samples of which only aadepth are distinct (both offsets use
-        // aax, main.cpp:775-785): each distinct ray is traced once and weighted by its multiplicity.
-        for (int aax = 0; aax < a.aadepth; aax++) {
-            HitRec rec;
-            bool want = false;
-            if (inside) {
-                rtm::D3 dd = rtm::camera_ray_dir(a.cam_dir, a.cam_right, a.cam_down, a.width, a.height, a.aadepth, x, y, aax);
-                R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
-                R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
-                R dist = R(1e9);
-                int id = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack);
-                if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
-                    double t = (double)dist;
-                    rec.pos[0] = a.cam_pos[0] + dd.x * t; rec.pos[1] = a.cam_pos[1] + dd.y * t; rec.pos[2] = a.cam_pos[2] + dd.z * t;   // :821
-                    rec.dir[0] = dd.x; rec.dir[1] = dd.y; rec.dir[2] = dd.z;
-                    rec.weight = (double)a.aadepth;
-                    rec.pixel = (uint32_t)((long long)yl * a.width + x);
-                    rec.obj = id;
-                    want = true;
+        // aax, main.cpp:775-785): without depth of field each distinct ray is traced once and weighted by
+        // its multiplicity.  With it every one of the aadepth^2 x dof_samples rays has its own lens jitter.
+        const bool dof = a.dof_samples > 1;
+        const int n_aay = dof ? a.aadepth : 1, n_dof = dof ? a.dof_samples : 1;
+        for (int aax = 0; aax < a.aadepth; aax++)
+            for (int aay = 0; aay < n_aay; aay++)
+                for (int ds = 0; ds < n_dof; ds++) {
+                    HitRec rec;
+                    bool want = false;
+                    if (inside) {
+                        rtm::D3 dd = rtm::camera_ray_dir(a.cam_dir, a.cam_right, a.cam_down, a.width, a.height, a.aadepth, x, y, aax);
+                        rtm::D3 org = {a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]}, dj = dd;
+                        if (dof) {                                                           // main.cpp:792-810
+                            rtm::D3 focal = rtm::vadd(org, rtm::vmul(dd, a.focal_len));
+                            rtm::D3 up = {0, 1, 0};
+                            rtm::D3 cam_up = rtm::vadd(up, rtm::vneg(rtm::vmul(dd, rtm::vdot(up, dd))));
+                            rtm::D3 cam_side = rtm::vcross(cam_up, dd);
+                            const uint32_t px = (uint32_t)((long long)y * a.width + x), draw = (uint32_t)(((aay * a.aadepth + aax) * n_dof + ds) * 2);
+                            double jx = -a.aperture + 2 * a.aperture * rtm::counter_uniform(px, draw, a.seed);
+                            double jy = -a.aperture + 2 * a.aperture * rtm::counter_uniform(px, draw + 1u, a.seed);
+                            org = rtm::vadd(rtm::vadd(org, rtm::vmul(cam_up, jx)), rtm::vmul(cam_side, jy));
+                            dj = rtm::vnorm(rtm::vadd(focal, rtm::vneg(org)));
+                        }
+                        R o[3] = {(R)org.x, (R)org.y, (R)org.z};
+                        R d[3] = {(R)dj.x, (R)dj.y, (R)dj.z};
+                        R dist = R(1e9);
+                        int id = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack);
+                        if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
+                            double t = (double)dist;
+                            // the jittered origin, but the un-jittered direction (main.cpp:821-822)
+                            rec.pos[0] = org.x + dd.x * t; rec.pos[1] = org.y + dd.y * t; rec.pos[2] = org.z + dd.z * t;
+                            rec.dir[0] = dd.x; rec.dir[1] = dd.y; rec.dir[2] = dd.z;
+                            rec.weight = dof ? 1.0 / n_dof : (double)a.aadepth;
+                            rec.pixel = (uint32_t)((long long)yl * a.width + x);
+                            rec.obj = id;
+                            want = true;
+                        }
+                    }
+                    push_hits(hits, &ctr->hits[1], shard_cap, want, rec, &ovf_queue);
                 }
-            }
-            push_hits(hits, &ctr->hits[1], shard_cap, want, rec, &ovf_queue);
-        }
     }
     if (ovf_stack) atomicMax(&ctr->overflow_stack, 1ull);
     if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
@@ -165,8 +193,13 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
         const uint32_t i = first + lane;
         const uint32_t in_window = in[(unsigned long long)shard * shard_cap + first].pixel >> 25;
         bool active = lane < (int)in_window;
-        RayRec next[2];
-        bool want[2] = {false, false};
+        // what the reflection / refraction loops of main.cpp:181-257 need, per hit
+        int n_samp = 0;                      // 0: no rays; 1; GLOSSY_SAMPLE for a glossy material
+        bool refr = false, refr_rest = false;
+        rtm::D3 hp{0, 0, 0}, Rd{0, 0, 0}, T0{0, 0, 0}, T1{0, 0, 0}, Nr{0, 0, 0}, Nf{0, 0, 0};
+        double w_refl = 0, w_refr = 0;
+        uint32_t pix = 0, key = 0;
+        int32_t from = 0;
         rtg::GatherRec g;
         bool want_g = false;
         if (active) {
@@ -181,33 +214,41 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
             double special = col[3];
             if (special > 0) {
                 if (!last_level) {   // children of the last level return black (main.cpp:161): not traced
-                    rtm::D3 Rd = rtm::reflect_dir(hit_normal, hit_dir);            // main.cpp:170
-                    next[0].org[0] = hit_pos.x; next[0].org[1] = hit_pos.y; next[0].org[2] = hit_pos.z;
-                    next[0].dir[0] = Rd.x; next[0].dir[1] = Rd.y; next[0].dir[2] = Rd.z;                  // main.cpp:190-191
-                    next[0].weight = special > 1 ? rec.weight * (2 - special) : rec.weight;              // main.cpp:200-203
-                    next[0].pixel = rec.pixel;
-                    next[0].obj = rec.obj;
-                    want[0] = true;
-                    if (special > 1) {                                             // main.cpp:210-258
-                        double refractance = special - 1;
+                    hp = hit_pos; pix = rec.pixel; from = rec.obj;
+                    key = rtm::path_key(hit_pos);
+                    n_samp = rtm::glossy_special(special) ? rtm::GLOSSY_SAMPLE : 1;          // main.cpp:177-179
+                    Rd = rtm::reflect_dir(hit_normal, hit_dir);                            // main.cpp:170
+                    Nr = hit_normal;
+                    w_refl = special > 1 ? rec.weight * (2 - special) : rec.weight;          // main.cpp:200-203
+                    if (special > 1) {                                                     // main.cpp:210-258
+                        w_refr = rec.weight * (special - 1);
                         double n1n2 = 1.0 / obj.ior;
                         double dot1 = rtm::vdot(hit_normal, rtm::vneg(hit_dir));
+                        Nf = hit_normal;
                         if (dot1 < 0) {
-                            hit_normal = rtm::vneg(hit_normal);
-                            dot1 = rtm::vdot(hit_normal, rtm::vneg(hit_dir));
+                            Nf = rtm::vneg(hit_normal);
+                            dot1 = rtm::vdot(Nf, rtm::vneg(hit_dir));
                             n1n2 = 1.0 / n1n2;
                         }
                         double nNL = n1n2 * dot1;
                         double underSQRT = 1 - n1n2 * n1n2 * (1 - dot1 * dot1);
                         if (underSQRT > 0) {
                             double coeffN = nNL - sqrt(underSQRT);
-                            rtm::D3 T = rtm::vadd(rtm::vmul(hit_normal, coeffN), rtm::vneg(rtm::vmul(rtm::vneg(hit_dir), n1n2)));   // main.cpp:233
-                            next[1].org[0] = hit_pos.x; next[1].org[1] = hit_pos.y; next[1].org[2] = hit_pos.z;
-                            next[1].dir[0] = T.x; next[1].dir[1] = T.y; next[1].dir[2] = T.z;            // main.cpp:242-243
-                            next[1].weight = rec.weight * refractance;                                   // main.cpp:251
-                            next[1].pixel = rec.pixel | RAY_REFRACT;
-                            next[1].obj = rec.obj;
-                            want[1] = true;
+                            T0 = rtm::vadd(rtm::vmul(Nf, coeffN), rtm::vneg(rtm::vmul(rtm::vneg(hit_dir), n1n2)));   // main.cpp:233
+                            refr = true;
+                        }
+                        // The loop of main.cpp:214 flips hit_normal in place, so from its second pass on the normal already
+                        // faces the ray and n1n2 stays 1 / ior even for a ray leaving the medium.
+                        {
+                            double n1n2b = 1.0 / obj.ior;
+                            double dot1b = rtm::vdot(Nf, rtm::vneg(hit_dir));
+                            double nNLb = n1n2b * dot1b;
+                            double under_b = 1 - n1n2b * n1n2b * (1 - dot1b * dot1b);
+                            if (under_b > 0) {
+                                double coeffN = nNLb - sqrt(under_b);
+                                T1 = rtm::vadd(rtm::vmul(Nf, coeffN), rtm::vneg(rtm::vmul(rtm::vneg(hit_dir), n1n2b)));
+                                refr_rest = true;
+                            }
                         }
                     }
                 }
@@ -241,8 +282,49 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
                 want_g = true;
             }
         }
-        rtq::push(rays, &ctr->rays[level], shard_cap, want[0], next[0], &ovf_queue);
-        rtq::push(rays, &ctr->rays[level], shard_cap, want[1], next[1], &ovf_queue);
+        // the sample loops: one reflection ray, and one refraction ray where there is one, per sample
+        const int wave_samples = __builtin_amdgcn_readfirstlane((int)rtk_wave_max(n_samp));
+        for (int i = 0; i < wave_samples; i++) {
+            RayRec next;
+            const bool mine = i < n_samp;
+            const bool glossy = n_samp > 1;
+            bool want = mine;
+            if (mine) {
+                rtm::D3 dir = Rd;
+                if (glossy) {
+                    const uint32_t draw = (uint32_t)(level * 1024 + i * 2);
+                    dir = rtm::glossy_ray(Rd, Nr, 0.2, rtm::counter_uniform(key, draw, a.seed), rtm::counter_uniform(key, draw + 1u, a.seed));   // main.cpp:183-184
+                }
+                next.org[0] = hp.x; next.org[1] = hp.y; next.org[2] = hp.z;
+                next.dir[0] = dir.x; next.dir[1] = dir.y; next.dir[2] = dir.z;                                // main.cpp:188
+                next.cont[0] = Rd.x; next.cont[1] = Rd.y; next.cont[2] = Rd.z;                                // main.cpp:195-196
+                next.weight = w_refl * (1.0 / n_samp);                                                        // main.cpp:207
+                next.pixel = pix;
+                next.obj = from;
+            }
+            rtq::push(rays, &ctr->rays[level], shard_cap, want, next, &ovf_queue);
+            const bool has = i == 0 ? refr : refr_rest;
+            want = mine && has;
+            if (want) {
+                const rtm::D3 T = i == 0 ? T0 : T1;
+                rtm::D3 dir = T;
+                if (glossy) {
+                    const uint32_t draw = (uint32_t)(level * 1024 + 512 + i * 2);
+                    dir = rtm::glossy_ray(T, Nf, 0.2, rtm::counter_uniform(key, draw, a.seed), rtm::counter_uniform(key, draw + 1u, a.seed));    // main.cpp:235-236
+                }
+                // main.cpp:255-256 scale the running sum and add it to the result inside the loop: sample i ends up
+                // with the weight sum_{t=1..n-i} n^-t (1 for a single sample)
+                double gw = 0, pw = 1;
+                for (int t = 0; t < n_samp - i; t++) { pw *= 1.0 / n_samp; gw += pw; }
+                next.org[0] = hp.x; next.org[1] = hp.y; next.org[2] = hp.z;
+                next.dir[0] = dir.x; next.dir[1] = dir.y; next.dir[2] = dir.z;                                // main.cpp:240
+                next.cont[0] = T.x; next.cont[1] = T.y; next.cont[2] = T.z;                                   // main.cpp:246-247
+                next.weight = w_refr * gw;                                                                    // main.cpp:251
+                next.pixel = pix | RAY_REFRACT;
+                next.obj = from;
+            }
+            rtq::push(rays, &ctr->rays[level], shard_cap, want, next, &ovf_queue);
+        }
         rtg::push_window(gq, &ctr->gather, shard_cap, want_g, g, &ovf_queue);
     }
     if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
@@ -281,7 +363,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
             double t = (double)dist;
             bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:193,245
             if (go) {
-                rtm::D3 org = {ray.org[0], ray.org[1], ray.org[2]}, dir = {ray.dir[0], ray.dir[1], ray.dir[2]};
+                rtm::D3 org = {ray.org[0], ray.org[1], ray.org[2]}, dir = {ray.cont[0], ray.cont[1], ray.cont[2]};
                 const bool refract = (ray.pixel & RAY_REFRACT) != 0;
                 rtm::D3 np = rtm::vadd(org, rtm::vmul(dir, refract ? a.accuracy + t : t));   // main.cpp:195, 246
                 next.pos[0] = np.x; next.pos[1] = np.y; next.pos[2] = np.z;

@@ -95,11 +95,15 @@ def test_lbvh_large_scene_and_render_path(gpu_ctx):
         else:   # float boxes are rounded, not widened: a hit within float rounding of a box face may be culled by one tree only
             assert (np.where(il >= 0, tl, 1e9) != np.where(ir >= 0, tr, 1e9)).mean() < 1e-3
     g = build_scene(rt.Scene(), "teapot_normal.obj", (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
-    p = rt.default_params(width=320, height=180, use_photon_map=0)
+    g.emit_photons(10000, seed=5)      # (no direct lighting in this renderer: a frame without photons is black)
+    gpu_ctx.photons_upload(g.photons_get())
+    p = rt.default_params(width=320, height=180, photon_num=10000, photon_use=50)
     gpu_ctx.upload(g)
     ref, _, _ = gpu_ctx.render(rt.look_at(CAM[:3], CAM[3:]), p)
+    assert ref.max() > 0.2
     gpu_ctx.upload_lbvh(g)
     got, _, st = gpu_ctx.render(rt.look_at(CAM[:3], CAM[3:]), p)
     a, b = np.floor(np.clip(got, 0, 1) * 255), np.floor(np.clip(ref, 0, 1) * 255)
-    assert (np.abs(a - b).max(-1) <= 1).mean() > 0.999
+    # (glass: refracted rays that start on a box face see the two trees differently, see test_gpu_scene_api)
+    assert (np.abs(a - b).max(-1) <= 1).mean() > 0.99
     assert st.secondary_rays > 0
