@@ -573,7 +573,8 @@ int build_photon_map_dev(rt_context* ctx, int which, long long n, const double* 
         const size_t used = std::min(n_bounds, (size_t)3 << level);
         HIP_TRY(hipMemsetAsync(mins, 0xFF, used * 4, ctx->stream));
         HIP_TRY(hipMemsetAsync(maxs, 0, used * 4, ctx->stream));
-        hipLaunchKernelGGL(rtkd::bounds_kernel, grid, dim3(T), 0, ctx->stream, src, ni, level, (const unsigned*)v0, mins, maxs);
+        hipLaunchKernelGGL(rtkd::bounds_kernel, dim3((unsigned)((n + (long long)T * rtkd::RUN - 1) / ((long long)T * rtkd::RUN))), dim3(T), 0, ctx->stream, src, ni, level,
+                           (const unsigned*)v0, mins, maxs);
         hipLaunchKernelGGL(rtkd::key_kernel, grid, dim3(T), 0, ctx->stream, src, ni, level, (const unsigned*)v0, (const unsigned*)mins, (const unsigned*)maxs, k0,
                            axis_at);
         HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + o_tmp, sort_bytes, k0, k1, v0, v1, ni, 0, key_bits, ctx->stream));

@@ -57,23 +57,19 @@ struct Source {
 };
 
 // mins[path * 3 + c] / maxs[path * 3 + c]: bounds of coordinate c (ordered bits) over range `path`.
-// Preset to all ones / zero.
+// Preset to all ones / zero.  A wave takes RUN consecutive steps of 64 positions and keeps the bounds
+// in registers for as long as the steps lie inside one range, so the top levels -- one or a few ranges
+// holding all the photons -- cost a few atomics per wave instead of a few per 64 photons (which took
+// 0.3 ms per level on 1.1 M photons: every atomic of a level lands on the same six words).
+constexpr int RUN = 32;
 __global__ void bounds_kernel(Source src, int n, int level, const unsigned* __restrict__ photon, unsigned* __restrict__ mins, unsigned* __restrict__ maxs)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in = i < n;
-    Where w = locate(in ? i : n - 1, n, level);
-    const bool part = in && !w.fixed && w.hi - w.lo > LEAF;
-    unsigned lo[3], hi[3];
-    for (int c = 0; c < 3; c++) { lo[c] = 0xFFFFFFFFu; hi[c] = 0u; }
-    if (part) {
-        const unsigned p = photon[i];
-        for (int c = 0; c < 3; c++) lo[c] = hi[c] = order_f32(src.coord(p, c));
-    }
-    // a wave whose first and last lanes sit in the same range lies inside it entirely
     const int lane = threadIdx.x & 63;
-    const int path0 = __shfl(part ? w.path : -1, 0), path63 = __shfl(part ? w.path : -2, 63);
-    if (path0 == path63) {
+    const long long wave = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    unsigned lo[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, hi[3] = {0u, 0u, 0u};
+    int held = -1;      // range whose bounds the registers hold (-1: none)
+    auto flush = [&]() {
+        if (held < 0) return;
         for (int c = 0; c < 3; c++)
             for (int off = 32; off > 0; off >>= 1) {
                 lo[c] = min(lo[c], (unsigned)__shfl_xor((int)lo[c], off));
@@ -81,15 +77,39 @@ __global__ void bounds_kernel(Source src, int n, int level, const unsigned* __re
             }
         if (lane == 0)
             for (int c = 0; c < 3; c++) {
-                atomicMin(&mins[(size_t)w.path * 3 + c], lo[c]);
-                atomicMax(&maxs[(size_t)w.path * 3 + c], hi[c]);
+                atomicMin(&mins[(size_t)held * 3 + c], lo[c]);
+                atomicMax(&maxs[(size_t)held * 3 + c], hi[c]);
             }
-    } else if (part) {
-        for (int c = 0; c < 3; c++) {
-            atomicMin(&mins[(size_t)w.path * 3 + c], lo[c]);
-            atomicMax(&maxs[(size_t)w.path * 3 + c], hi[c]);
+        for (int c = 0; c < 3; c++) { lo[c] = 0xFFFFFFFFu; hi[c] = 0u; }
+        held = -1;
+    };
+    for (int r = 0; r < RUN; r++) {
+        const long long i = (wave * RUN + r) * 64 + lane;
+        if ((wave * RUN + r) * 64 >= n) break;
+        const bool in = i < n;
+        Where w = locate(in ? (int)i : n - 1, n, level);
+        const bool part = in && !w.fixed && w.hi - w.lo > LEAF;
+        unsigned v[3] = {0, 0, 0};
+        if (part) {
+            const unsigned p = photon[i];
+            for (int c = 0; c < 3; c++) v[c] = order_f32(src.coord(p, c));
+        }
+        // a step whose first and last lanes sit in the same range lies inside it entirely
+        const int path0 = __shfl(part ? w.path : -1, 0), path63 = __shfl(part ? w.path : -2, 63);
+        if (path0 == path63) {
+            if (held != path0) flush();
+            held = path0;
+            for (int c = 0; c < 3; c++) { lo[c] = min(lo[c], v[c]); hi[c] = max(hi[c], v[c]); }
+        } else {
+            flush();
+            if (part)
+                for (int c = 0; c < 3; c++) {
+                    atomicMin(&mins[(size_t)w.path * 3 + c], v[c]);
+                    atomicMax(&maxs[(size_t)w.path * 3 + c], v[c]);
+                }
         }
     }
+    flush();
 }
 
 __global__ void key_kernel(Source src, int n, int level, const unsigned* __restrict__ photon, const unsigned* __restrict__ mins,
