@@ -176,6 +176,27 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
     if (ovf_queue) atomicMax(&ctr->overflow_queue, 1ull);
 }
 
+// The ray queue in windows, too: the rays one shading wave spawns in one sample slot (one kind, one tile's
+// hit points) are traced by one wave.  The first record carries count - 1 in bits 25..30 of `pixel`.
+__device__ __forceinline__ void push_rays(RayRec* q, rtq::Counts* cnt, unsigned long long shard_cap, bool want, RayRec& rec, unsigned long long* overflow)
+{
+    unsigned long long m = __ballot(want);
+    if (m == 0) return;
+    const unsigned shard = rtq::wave_index() & (rtq::SHARDS - 1);
+    const int leader = __builtin_ctzll(m);
+    unsigned long long base = 0;
+    if ((int)rtq::lane_id() == leader) {
+        base = atomicAdd(&cnt->n[shard][0], (unsigned long long)WAVE);
+        rec.pixel |= (uint32_t)(__builtin_popcountll(m) - 1) << 25;
+    }
+    unsigned lo = __shfl((unsigned)base, leader), hi = __shfl((unsigned)(base >> 32), leader);
+    base = ((unsigned long long)hi << 32) | lo;
+    if (want) {
+        if (base + WAVE <= shard_cap) q[(unsigned long long)shard * shard_cap + base + rtq::prefix_rank(m)] = rec;
+        else *overflow = 1;
+    }
+}
+
 // One recursion level of getColorAt for every queued hit, up to the point where it would call Shoot.
 __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a, int level, int last_level, const HitRec* __restrict__ in,
                                                       RayRec* __restrict__ rays, rtg::GatherRec* __restrict__ gq, unsigned long long shard_cap,
@@ -302,7 +323,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
                 next.pixel = pix;
                 next.obj = from;
             }
-            rtq::push(rays, &ctr->rays[level], shard_cap, want, next, &ovf_queue);
+            push_rays(rays, &ctr->rays[level], shard_cap, want, next, &ovf_queue);
             const bool has = i == 0 ? refr : refr_rest;
             want = mine && has;
             if (want) {
@@ -323,7 +344,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
                 next.pixel = pix | RAY_REFRACT;
                 next.obj = from;
             }
-            rtq::push(rays, &ctr->rays[level], shard_cap, want, next, &ovf_queue);
+            push_rays(rays, &ctr->rays[level], shard_cap, want, next, &ovf_queue);
         }
         rtg::push_window(gq, &ctr->gather, shard_cap, want_g, g, &ovf_queue);
     }
@@ -351,10 +372,12 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
         uint32_t first, n_shard;
         rtq::locate(map, chunk, WAVE, shard, first, n_shard);
         const uint32_t i = first + st.lane;
+        const uint32_t in_window = ((rays[(unsigned long long)shard * shard_cap + first].pixel >> 25) & 63u) + 1u;
         HitRec next;
         bool want = false;
-        if (i < n_shard) {
-            const RayRec ray = rays[(unsigned long long)shard * shard_cap + i];
+        if (st.lane < (int)in_window) {
+            RayRec ray = rays[(unsigned long long)shard * shard_cap + i];
+            ray.pixel &= HIT_PIXEL_MASK | RAY_REFRACT;
             R o[3] = {(R)ray.org[0], (R)ray.org[1], (R)ray.org[2]};
             R d[3] = {(R)ray.dir[0], (R)ray.dir[1], (R)ray.dir[2]};
             R dist = R(1e9);
