@@ -61,7 +61,7 @@ class Scene:
         self.h = h
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:      # (module globals are gone at interpreter shutdown)
             lib.rt_scene_destroy(self.h)
             self.h = None
 
@@ -152,7 +152,7 @@ class Context:
         self.device = device
 
     def __del__(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.rt_context_destroy(self.h)
             self.h = None
 
