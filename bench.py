@@ -242,6 +242,10 @@ def main():
             "bytes_per_ray": round(alg_bytes / rank_rays, 1),
             "inner_visits_per_ray": round(st_work.inner_visits / rank_rays, 3),
             "prim_tests_per_ray": round(st_work.prim_tests / rank_rays, 3),
+            # the resource that actually binds (informational): arithmetic of the reference's operation order, no FMA
+            # (slab test 21 flop, Moeller-Trumbore 51 flop) against the vector rate without FMA (half of 78.6 / 157.3 TFLOP/s)
+            "valu": {"algorithmic_tflops": round(((rank_rays + 2 * st_work.inner_visits) * 21 + st_work.prim_tests * 51) / (avg_kernel_ms * 1e-3) / 1e12, 3),
+                     "peak_tflops_no_fma": 39.3 if prec == rt.RT_F64 else 78.6},
             "note": "algorithmic bytes = inner-node visits x node record + primitive tests x primitive record (measured by the instrumented kernel); "
                     "the scene is cache-resident, so this prices the path against HBM peak as if every record came from memory",
         },
