@@ -113,7 +113,8 @@ int use_device(rt_context* ctx)
     return RT_OK;
 }
 
-int stack_cap(const rt_context* ctx) { return ctx->depth + 2; }
+// deepest path: `depth` inner nodes, one deferred sibling each
+int stack_cap(const rt_context* ctx) { return std::max(1, ctx->depth); }
 
 template <class R>
 const rtf::SceneView<R>& view(const rt_context* ctx);
@@ -131,7 +132,7 @@ template <class R>
 int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* d_dir, double* d_dist, int32_t* d_ids)
 {
     int cap = stack_cap(ctx);
-    size_t lds = rtk::stack_lds_bytes(cap, sizeof(R));
+    size_t lds = rtk::stack_lds_bytes(cap, sizeof(float));
     if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
     HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
     int blocks = (int)std::max<int64_t>(1, (n + rtk::BLOCK - 1) / rtk::BLOCK);   // one chunk of 64 rays per wave
@@ -154,7 +155,7 @@ int gather_front_cap()
 }
 
 template <class R>
-int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g)
+int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g, int vgpr_waves = 12)
 {
     // Blocks of 4 waves (one 8x8 tile each) unless a deep tree's stacks then leave fewer waves resident
     // than smaller blocks would (LDS is the limit: depth x 64 lanes x bytes per entry, per wave).
@@ -163,12 +164,13 @@ int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g)
     // (TRAV_NODES) when the copy is cheap next to the block's work and leaves room for 3 blocks per CU.
     const int cap = stack_cap(ctx);
     const size_t lds_max = 160 * 1024;
-    const int vgpr_waves = 12;   // waves per CU the register budget of the traversal kernels admits
+    // vgpr_waves: waves per CU the register budget of the kernel family admits (12 for the render path's kernels
+    // at up to 168 registers; the primary-ray kernels need about 100 and 75)
     int best_w = 0, best_resident = 0, best_mode = rtk::TRAV_PLAIN;
     const char* force = getenv("RT_TRAV_MODE");   // tuning aid: "plain" / "retest"
     for (int mode : {rtk::TRAV_PLAIN, rtk::TRAV_RETEST}) {
         if (force && ((force[0] == 'p') != (mode == rtk::TRAV_PLAIN))) continue;
-        const size_t per_wave = rtk::stack_lds_bytes(cap, mode == rtk::TRAV_RETEST ? 0 : sizeof(R), 1);
+        const size_t per_wave = rtk::stack_lds_bytes(cap, mode == rtk::TRAV_RETEST ? 0 : sizeof(float), 1);
         for (int w : {4, 2, 1}) {
             size_t lds = w * per_wave;
             if (lds > lds_max) continue;
@@ -176,13 +178,17 @@ int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g)
             if (resident > best_resident) { best_resident = resident; best_w = w; best_mode = mode; }
         }
     }
+    if (const char* fw = getenv("RT_BLOCK_WAVES")) best_w = std::max(1, std::min(12, atoi(fw)));   // tuning aid
     if (!best_w) return fail(RT_ERR_LIMIT, "BVH depth %d: the traversal stack of one wave does not fit 160 KiB of LDS", ctx->depth);
-    size_t lds = best_w * rtk::stack_lds_bytes(cap, best_mode == rtk::TRAV_RETEST ? 0 : sizeof(R), 1);
+    size_t lds = best_w * rtk::stack_lds_bytes(cap, best_mode == rtk::TRAV_RETEST ? 0 : sizeof(float), 1);
     const size_t node_bytes = rtk::node_lds_bytes<R>((size_t)n_nodes);
-    if (best_mode == rtk::TRAV_PLAIN && best_w == 4 && n_nodes > 0 && node_bytes <= 24 * 1024 && 3 * (lds + node_bytes) <= lds_max && !getenv("RT_NO_NODE_LDS")) {
+    if (best_mode == rtk::TRAV_PLAIN && best_w >= 4 && n_nodes > 0 && node_bytes <= 32 * 1024 && 2 * (lds + node_bytes) <= lds_max && !getenv("RT_NO_NODE_LDS")) {
         best_mode = rtk::TRAV_NODES;
         lds += node_bytes;
     }
+    if (getenv("RT_TRACE_GEOM"))
+        fprintf(stderr, "trace geometry: %d waves per block, %zu B of LDS (%zu B node image), mode %d, depth %d, up to %d waves per CU by registers\n", best_w, lds,
+                best_mode == rtk::TRAV_NODES ? node_bytes : (size_t)0, best_mode, ctx->depth, vgpr_waves);
     *g = TraceGeom{best_w * 64, 0, lds, best_mode};
     return RT_OK;
 }
@@ -457,7 +463,7 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
 {
     int rc;
     const int cap = stack_cap(ctx);
-    const size_t lds = rtk::stack_lds_bytes(cap, sizeof(double));
+    const size_t lds = rtk::stack_lds_bytes(cap, sizeof(float));
     if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
     const int64_t batch = 1 << 20;
     // a photon stores at most once per bounce level, and scatters at most 4 volume photons (a subsurface hit ends the walk)

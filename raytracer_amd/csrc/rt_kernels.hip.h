@@ -135,6 +135,18 @@ __device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims
 //     what the pop compares (t0 travels on the stack);
 //   - rays with a non-finite reciprocal direction or origin (axis-parallel rays: 0 * inf = NaN in
 //     the slab test) take the literal path below, which re-runs the full slab test on entry.
+// Entry distance of a deferred child as kept on the stack: a float not above the value.  The pop test
+// "entry distance > current best" skips a subtree; with the distance rounded DOWN the test can only fail to
+// skip, and a subtree entered needlessly holds no hit closer than the best (its hits lie beyond its entry
+// distance), so results are unchanged while a stack entry takes 8 bytes instead of 12.
+template <class R>
+__device__ __forceinline__ float entry_floor(R t)
+{
+    float f = (float)t;
+    if ((R)f > t) f = __uint_as_float(__float_as_uint(f) + (f > 0.f ? -1 : 1));     // next float toward -inf (f != 0 here: f > t >= 0 or t < 0)
+    return f;
+}
+
 template <class R, bool COUNT = false, bool TRI_ONLY = false, int MODE = TRAV_PLAIN>
 __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R& dist, const LaneStack& st, uint32_t* overflow,
                          WorkCount* wc = nullptr)
@@ -142,7 +154,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
     if (d[0] != d[0]) return -1;   // BVH.cpp:110-115
     int hit = -1;
     uint32_t* s_ref = st.ref;
-    R* s_t0 = (R*)st.t0;
+    float* s_t0 = (float*)st.t0;
     const int lane = st.lane;
 
     if (sv.root_ref != rtf::NO_NODE) {
@@ -168,7 +180,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                                     s_ref[sp * WAVE + lane] = (cur << 1) | (first0 ? 1u : 0u);
                                 } else {
                                     s_ref[sp * WAVE + lane] = first0 ? c1 : c0;
-                                    s_t0[sp * WAVE + lane] = first0 ? td1 : td0;
+                                    s_t0[sp * WAVE + lane] = entry_floor<R>(first0 ? td1 : td0);
                                 }
                                 sp++;
                             } else {
@@ -193,7 +205,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                             for (int i = 0; i < 3; i++) { lo[i] = second ? pn.lo1[i] : pn.lo0[i]; hi[i] = second ? pn.hi1[i] : pn.hi0[i]; }
                             if (!(rtm::slab_finite<R>(lo, hi, o, inv, dist) < R(0))) { cur = second ? pn.c1 : pn.c0; found = true; break; }   // BVH.cpp:132
                         } else {
-                            const R t0 = s_t0[sp * WAVE + lane];
+                            const R t0 = (R)s_t0[sp * WAVE + lane];
                             const uint32_t ref = s_ref[sp * WAVE + lane];     // read with t0, not after the comparison
                             if (!(t0 > dist)) { cur = ref; found = true; break; }
                         }
@@ -202,12 +214,16 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                 }
             }
         } else {
-            // literal emulation of the recursion; stack entries are (parent node << 1 | which child)
+            // literal emulation of the recursion; stack entries are (parent node << 1 | which child).  At an inner
+            // node the second child waits on the stack and the first is entered at once, so a path of `depth`
+            // inner nodes holds at most `depth` entries, as in the walk above.
             if (!(rtm::slab_literal<R>(sv.root_lo, sv.root_hi, o, d, dist) < R(0))) {
                 int sp = 0;
                 uint32_t cur = sv.root_ref;
                 bool have = true;
                 while (true) {
+                    uint32_t e = 0;
+                    bool direct = false;
                     if (have) {
                         if (cur & rtf::LEAF_BIT) {
                             test_leaf<R, COUNT, TRI_ONLY>(sv.prims, cur, o, d, dist, hit, wc);
@@ -217,19 +233,21 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                             R td0 = rtm::slab_literal<R>(nd.lo0, nd.hi0, o, d, dist);
                             R td1 = rtm::slab_literal<R>(nd.lo1, nd.hi1, o, d, dist);
                             uint32_t first = td0 < td1 ? 0u : 1u;
-                            if (sp + 2 <= st.cap) {
+                            if (sp < st.cap) {
                                 s_ref[sp * WAVE + lane] = (cur << 1) | (1u - first);
-                                sp++;
-                                s_ref[sp * WAVE + lane] = (cur << 1) | first;
                                 sp++;
                             } else {
                                 *overflow = 1;
                             }
+                            e = (cur << 1) | first;
+                            direct = true;
                         }
                     }
-                    if (sp == 0) break;
-                    sp--;
-                    uint32_t e = s_ref[sp * WAVE + lane];
+                    if (!direct) {
+                        if (sp == 0) break;
+                        sp--;
+                        e = s_ref[sp * WAVE + lane];
+                    }
                     const rtf::Node<R>& pn = sv.nodes[e >> 1];
                     bool second = e & 1u;
                     const R* lo = second ? pn.lo1 : pn.lo0;
@@ -249,7 +267,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
     return hit;
 }
 
-// LDS layout of a block: [node image (node_bytes, may be 0)] [refs: waves x cap x 64 x 4 B] [t0: waves x cap x 64 x sizeof(R)]
+// LDS layout of a block: [node image (node_bytes, may be 0)] [refs: waves x cap x 64 x 4 B] [t0: waves x cap x 64 x 4 B]
 template <class R>
 __device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, size_t node_bytes = 0)
 {
@@ -259,7 +277,7 @@ __device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, siz
     st.lds_nodes = reinterpret_cast<const uint4*>(lds);
     unsigned char* base = lds + node_bytes;
     st.ref = (uint32_t*)base + (size_t)wave * cap * WAVE;
-    st.t0 = (void*)((R*)(base + (size_t)waves * cap * WAVE * sizeof(uint32_t)) + (size_t)wave * cap * WAVE);
+    st.t0 = (void*)((float*)(base + (size_t)waves * cap * WAVE * sizeof(uint32_t)) + (size_t)wave * cap * WAVE);
     st.lane = lane;
     st.cap = cap;
     return st;
