@@ -1203,7 +1203,7 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     int rc;
     if (prof && (rc = ctx->st_aux.reserve(rtg::TP_SLOTS * 8))) return rc;
     if (prof) HIP_TRY(hipMemsetAsync(ctx->st_aux.p, 0, rtg::TP_SLOTS * 8, ctx->stream));
-    rtg::TileArgs ta{recs, cnt, shard_cap, next_window, (uint32_t*)ctx->redo.p, n_redo, (mode && mode[0] == 'q') ? 1 : 0,
+    rtg::TileArgs ta{recs, cnt, shard_cap, next_window, (uint32_t*)ctx->redo.p, n_redo, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
                      prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
     hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gp, d_acc);
     HIP_TRY(hipGetLastError());
