@@ -201,9 +201,8 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
     int rc = trace_geometry<R>(ctx, ctx->n_nodes, &g);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
-    int64_t tiles = (int64_t)((a.width + 7) / 8) * ((a.row_end - a.row_begin + 7) / 8);
     int wpb = g.threads / 64;
-    int blocks = (int)std::max<int64_t>(1, (tiles + wpb - 1) / wpb);
+    int blocks = (int)rtk::tile_grid_blocks((a.width + 7) / 8, (a.row_end - a.row_begin + 7) / 8, wpb, g.mode == rtk::TRAV_NODES);
 #define RT_LAUNCH_PRIMARY(MODE)                                                                                                              \
     hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, \
                        d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes)
@@ -1231,9 +1230,8 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     const int rows = a.row_end - a.row_begin;
     const int cap = stack_cap(ctx);
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
-    const int64_t tiles = (int64_t)((a.width + 7) / 8) * ((rows + 7) / 8);
     const int wpb = g.threads / 64;
-    hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE>), dim3((unsigned)((tiles + wpb - 1) / wpb)), dim3(g.threads), g.lds, ctx->stream,
+    hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE>), dim3((unsigned)rtk::tile_grid_blocks((a.width + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES)), dim3(g.threads), g.lds, ctx->stream,
                        view<R>(ctx), a, (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes);
     HIP_TRY(hipGetLastError());
     // persistent grids for the queue consumers (their work counts live in device memory)

@@ -121,11 +121,9 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
     unsigned long long ovf_queue = 0;
     const int rows = a.row_end - a.row_begin;
     const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
-    const unsigned long long n_tiles = (unsigned long long)tiles_x * tiles_y;
     // one 8x8 tile per wave; the dispatcher balances the load
-    const unsigned long long tile = (unsigned long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile < n_tiles) {
-        int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+    int tx, ty;
+    if (rtk::tile_of_wave<MODE == rtk::TRAV_NODES>(tiles_x, tiles_y, &tx, &ty)) {
         int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
         bool inside = x < a.width && yl < rows;
         int yc = a.row_begin + yl;
