@@ -107,6 +107,9 @@ int rt_context_create(int device, rt_context** out);
 void rt_context_destroy(rt_context* ctx);
 /* the HIP stream (hipStream_t) all work of this context is enqueued on */
 void* rt_context_stream(rt_context* ctx);
+/* Waits for the context's stream.  The *_dev entry points called without `stats` do not wait for their
+ * kernels; if one of those kernels ran out of traversal stack or queue room (its output is then incomplete)
+ * the device remembers it and this call returns RT_ERR_LIMIT, once.  Calls that do wait report it themselves. */
 int rt_context_synchronize(rt_context* ctx);
 void rt_default_params(rt_render_params* p);
 /* camera basis from position + look-at, main.cpp:626-635 */

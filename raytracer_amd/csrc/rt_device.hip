@@ -121,6 +121,25 @@ const rtf::SceneView<R>& view(const rt_context* ctx);
 template <> const rtf::SceneView<double>& view<double>(const rt_context* ctx) { return ctx->v64; }
 template <> const rtf::SceneView<float>& view<float>(const rt_context* ctx) { return ctx->v32; }
 
+// The device's overflow latch (the stream must be idle): read into v and cleared when set.
+int take_overflow_latch(unsigned long long v[2])
+{
+    HIP_TRY(hipMemcpyFromSymbol(v, HIP_SYMBOL(rtk::g_overflow_latch), 2 * sizeof(unsigned long long)));
+    if (v[0] | v[1]) {
+        const unsigned long long zero[2] = {0, 0};
+        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtk::g_overflow_latch), zero, sizeof zero));
+    }
+    return RT_OK;
+}
+
+// An overflow found in a call's own counters: reported now, so the latch is cleared with it.
+int overflow_error(const char* what)
+{
+    unsigned long long v[2];
+    int rc = take_overflow_latch(v);
+    return rc ? rc : fail(RT_ERR_LIMIT, "%s", what);
+}
+
 int read_counters(rt_context* ctx, rtk::TraceCounters* out)
 {
     HIP_TRY(hipMemcpyAsync(out, ctx->counters.p, sizeof(*out), hipMemcpyDeviceToHost, ctx->stream));
@@ -295,7 +314,13 @@ void* rt_context_stream(rt_context* ctx) { return ctx ? (void*)ctx->stream : nul
 int rt_context_synchronize(rt_context* ctx)
 {
     if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
+    int rc = use_device(ctx);
+    if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long v[2];
+    if ((rc = take_overflow_latch(v))) return rc;
+    if (v[0]) return fail(RT_ERR_LIMIT, "traversal stack overflow in an earlier call on this device");
+    if (v[1]) return fail(RT_ERR_LIMIT, "bounce/gather/photon queue overflow in an earlier call on this device");
     return RT_OK;
 }
 
@@ -492,8 +517,8 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
         rte::EmitCounters hc;
         HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (hc.overflow_stack) return fail(RT_ERR_LIMIT, "traversal stack overflow");
-        if (hc.overflow_queue) return fail(RT_ERR_LIMIT, "photon queue overflow");
+        if (hc.overflow_stack) return overflow_error("traversal stack overflow");
+        if (hc.overflow_queue) return overflow_error("photon queue overflow");
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         ms_total += ms;
@@ -959,7 +984,7 @@ int rt_trace_closest(rt_context* ctx, int precision, int64_t n, const double* or
     HIP_TRY(hipMemcpyAsync(ids, ctx->st_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     rtk::TraceCounters c;
     if ((rc = read_counters(ctx, &c))) return rc;
-    if (c.overflow) return fail(RT_ERR_LIMIT, "traversal stack overflow");
+    if (c.overflow) return overflow_error("traversal stack overflow");
     return RT_OK;
 }
 
@@ -992,7 +1017,7 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
     if (stats) {
         rtk::TraceCounters c;
         if ((rc = read_counters(ctx, &c))) return rc;
-        if (c.overflow) return fail(RT_ERR_LIMIT, "traversal stack overflow");
+        if (c.overflow) return overflow_error("traversal stack overflow");
         memset(stats, 0, sizeof(*stats));
         stats->primary_rays = (uint64_t)p->width * (uint64_t)(row_end - row_begin);
         stats->shadow_rays = c.shadow;
@@ -1266,7 +1291,9 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     // (a glossy hit spawns 16 + 16 rays: such scenes are rendered in small row blocks with room for two glossy bounces in a row)
     const unsigned long long cap_hits = samples << (ctx->has_glossy && levels > 1 ? 10 : std::max(0, std::min(levels - 1, 3)));
     // (a multiple of 64: the gather queue is filled in whole windows of 64 slots)
-    const unsigned long long shard_cap = (((cap_hits + rtq::SHARDS - 1) / rtq::SHARDS + 16384) + 63) & ~63ull;
+    unsigned long long shard_cap = (((cap_hits + rtq::SHARDS - 1) / rtq::SHARDS + 16384) + 63) & ~63ull;
+    // RT_SHARD_CAP=<slots>: a smaller queue, to exercise the overflow report (development aid)
+    if (const char* e = getenv("RT_SHARD_CAP")) shard_cap = std::max<unsigned long long>(64, (strtoull(e, nullptr, 10) + 63) & ~63ull);
     const unsigned long long cap_total = shard_cap * rtq::SHARDS;
     int rc;
     if ((rc = ctx->hits_a.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
@@ -1370,8 +1397,8 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     if (stats) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         for (size_t i = 0; i < ci; i++) {
-            if (hc[i].overflow_stack) return fail(RT_ERR_LIMIT, "traversal stack overflow");
-            if (hc[i].overflow_queue) return fail(RT_ERR_LIMIT, "bounce/gather queue overflow");
+            if (hc[i].overflow_stack) return overflow_error("traversal stack overflow");
+            if (hc[i].overflow_queue) return overflow_error("bounce/gather queue overflow");
             total.secondary_rays += hc[i].secondary_rays;
             for (int sh = 0; sh < rtq::SHARDS; sh++) total.gather_queries += hc[i].gather.n[sh][1];
             total.gather_single += hc[i].n_redo;

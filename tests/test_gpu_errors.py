@@ -110,3 +110,32 @@ def test_volume_map_without_surface_map(teapot):
     rgb, bgr, st = ctx.render(cam, rt.default_params(width=64, height=64))
     assert (bgr == 0).all() and np.isfinite(rgb).all()
     ctx.photons_upload(np.zeros((0, 9)), 1)
+
+
+def test_queue_overflow_is_reported(monkeypatch):
+    """A bounce queue too small for the frame (forced through RT_SHARD_CAP): the call that waits reports it itself, the
+    call that does not wait leaves it to the next synchronize, and the report is made once."""
+    ctx = rt.Context(0)
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")                                # the runtime the library itself uses
+    d_rgb = ctypes.c_void_p()
+    n_bytes = 256 * 256 * 3 * 8
+    assert hip.hipMalloc(ctypes.byref(d_rgb), ctypes.c_size_t(n_bytes)) == 0
+    ctx.upload(build_scene(rt.Scene(), rgbs=(1.0, 1.0, 1.0, 1.8), ior=1.5))           # glass teapot: every hit spawns two rays
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    p = rt.default_params(width=256, height=256, use_photon_map=0)
+    ctx.render(cam, p)                                                               # fits: no error
+    ctx.synchronize()
+    monkeypatch.setenv("RT_SHARD_CAP", "64")
+    assert code_of(ctx.render, cam, p) == LIMIT
+    ctx.synchronize()                                                                # already reported
+    ctx.render_dev(cam, p, (0, 256), d_rgb, None, stats=False)                       # does not wait, returns OK
+    assert code_of(ctx.synchronize) == LIMIT
+    ctx.synchronize()                                                                # reported once
+    monkeypatch.delenv("RT_SHARD_CAP")
+    ref, _, _ = ctx.render(cam, p)
+    ctx.render_dev(cam, p, (0, 256), d_rgb, None, stats=False)
+    ctx.synchronize()
+    out = np.zeros((256, 256, 3))
+    assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), d_rgb, ctypes.c_size_t(n_bytes), 2) == 0      # device to host
+    assert hip.hipFree(d_rgb) == 0
+    assert np.abs(out - ref).max() < 1e-12
