@@ -134,6 +134,7 @@ def main():
         e1.record(ext)
         barrier()
         dt = time.perf_counter() - t0
+        ctx.synchronize()                        # (raises if a kernel of the untimed-for-errors launches above overflowed)
         rays = torch.tensor([float(st.primary_rays + st.shadow_rays)], dtype=torch.float64, device=dev)
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         if world > 1:
