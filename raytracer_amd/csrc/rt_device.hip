@@ -1256,7 +1256,7 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     const int cap = stack_cap(ctx);
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int wpb = g.threads / 64;
-    hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE>), dim3((unsigned)rtk::tile_grid_blocks((a.width + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES)), dim3(g.threads), g.lds, ctx->stream,
+    hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE>), dim3((unsigned)rtk::tile_grid_blocks((a.width + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth)), dim3(g.threads), g.lds, ctx->stream,
                        view<R>(ctx), a, (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes);
     HIP_TRY(hipGetLastError());
     // persistent grids for the queue consumers (their work counts live in device memory)

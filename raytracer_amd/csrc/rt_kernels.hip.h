@@ -335,26 +335,31 @@ struct PrimaryArgs {
 //    the compact order lowers L1/L2 misses but leaves fewer waves resident on average (3.0 instead of 3.6 per
 //    SIMD) and the frame takes 9 % longer, so such scenes keep this order.
 constexpr int SB_TX = 16, SB_TY = 8, SB_TILES = SB_TX * SB_TY, N_XCD = 8;
-__host__ __device__ inline long long tile_grid_blocks(int tiles_x, int tiles_y, int waves_per_block, bool compact)
+// (`split` consecutive waves share a tile: wave `*part` of them takes that share of the tile's samples)
+__host__ __device__ inline long long tile_grid_blocks(int tiles_x, int tiles_y, int waves_per_block, bool compact, int split = 1)
 {
-    if (!compact) return ((long long)tiles_x * tiles_y + waves_per_block - 1) / waves_per_block;
+    if (!compact) return ((long long)tiles_x * tiles_y * split + waves_per_block - 1) / waves_per_block;
     const long long n_sb = (long long)((tiles_x + SB_TX - 1) / SB_TX) * ((tiles_y + SB_TY - 1) / SB_TY);
-    const long long per_xcd = (n_sb + N_XCD - 1) / N_XCD * SB_TILES;                 // tiles (with padding) one XCD walks
+    const long long per_xcd = (n_sb + N_XCD - 1) / N_XCD * SB_TILES * split;         // waves (with padding) one XCD runs
     return (per_xcd + waves_per_block - 1) / waves_per_block * N_XCD;
 }
 template <bool COMPACT>
-__device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, int* ty)
+__device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, int* ty, unsigned split = 1, int* part = nullptr)
 {
     const unsigned wpb = blockDim.x >> 6;
     if (!COMPACT) {
-        const unsigned long long tile = (unsigned long long)blockIdx.x * wpb + (threadIdx.x >> 6);
+        const unsigned long long w = (unsigned long long)blockIdx.x * wpb + (threadIdx.x >> 6);
+        const unsigned long long tile = w / split;
+        if (part) *part = (int)(w % split);
         if (tile >= (unsigned long long)tiles_x * tiles_y) return false;
         *tx = (int)(tile % (unsigned)tiles_x);
         *ty = (int)(tile / (unsigned)tiles_x);
         return true;
     }
     const unsigned xcd = blockIdx.x % N_XCD, slot = blockIdx.x / N_XCD;
-    const unsigned long long q = (unsigned long long)slot * wpb + (threadIdx.x >> 6);
+    const unsigned long long w = (unsigned long long)slot * wpb + (threadIdx.x >> 6);
+    const unsigned long long q = w / split;
+    if (part) *part = (int)(w % split);
     const unsigned long long sb = q / SB_TILES * N_XCD + xcd;
     const unsigned m = (unsigned)(q % SB_TILES);
     const unsigned sbx = (unsigned)(tiles_x + SB_TX - 1) / SB_TX, sby = (unsigned)(tiles_y + SB_TY - 1) / SB_TY;

@@ -121,9 +121,10 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
     unsigned long long ovf_queue = 0;
     const int rows = a.row_end - a.row_begin;
     const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
-    // one 8x8 tile per wave; the dispatcher balances the load
-    int tx, ty;
-    if (rtk::tile_of_wave<MODE == rtk::TRAV_NODES>(tiles_x, tiles_y, &tx, &ty)) {
+    // one 8x8 tile and one of its aadepth sample columns per wave (the waves of a tile are neighbours in a block,
+    // so they share its nodes and triangles in L1); the dispatcher balances the load
+    int tx, ty, aax;
+    if (rtk::tile_of_wave<MODE == rtk::TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, (unsigned)a.aadepth, &aax)) {
         int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
         bool inside = x < a.width && yl < rows;
         int yc = a.row_begin + yl;
@@ -133,42 +134,41 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
         // its multiplicity.  With it every one of the aadepth^2 x dof_samples rays has its own lens jitter.
         const bool dof = a.dof_samples > 1;
         const int n_aay = dof ? a.aadepth : 1, n_dof = dof ? a.dof_samples : 1;
-        for (int aax = 0; aax < a.aadepth; aax++)
-            for (int aay = 0; aay < n_aay; aay++)
-                for (int ds = 0; ds < n_dof; ds++) {
-                    HitRec rec;
-                    bool want = false;
-                    if (inside) {
-                        rtm::D3 dd = rtm::camera_ray_dir(a.cam_dir, a.cam_right, a.cam_down, a.width, a.height, a.aadepth, x, y, aax);
-                        rtm::D3 org = {a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]}, dj = dd;
-                        if (dof) {                                                           // main.cpp:792-810
-                            rtm::D3 focal = rtm::vadd(org, rtm::vmul(dd, a.focal_len));
-                            rtm::D3 up = {0, 1, 0};
-                            rtm::D3 cam_up = rtm::vadd(up, rtm::vneg(rtm::vmul(dd, rtm::vdot(up, dd))));
-                            rtm::D3 cam_side = rtm::vcross(cam_up, dd);
-                            const uint32_t px = (uint32_t)((long long)y * a.width + x), draw = (uint32_t)(((aay * a.aadepth + aax) * n_dof + ds) * 2);
-                            double jx = -a.aperture + 2 * a.aperture * rtm::counter_uniform(px, draw, a.seed);
-                            double jy = -a.aperture + 2 * a.aperture * rtm::counter_uniform(px, draw + 1u, a.seed);
-                            org = rtm::vadd(rtm::vadd(org, rtm::vmul(cam_up, jx)), rtm::vmul(cam_side, jy));
-                            dj = rtm::vnorm(rtm::vadd(focal, rtm::vneg(org)));
-                        }
-                        R o[3] = {(R)org.x, (R)org.y, (R)org.z};
-                        R d[3] = {(R)dj.x, (R)dj.y, (R)dj.z};
-                        R dist = R(1e9);
-                        int id = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack);
-                        if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
-                            double t = (double)dist;
-                            // the jittered origin, but the un-jittered direction (main.cpp:821-822)
-                            rec.pos[0] = org.x + dd.x * t; rec.pos[1] = org.y + dd.y * t; rec.pos[2] = org.z + dd.z * t;
-                            rec.dir[0] = dd.x; rec.dir[1] = dd.y; rec.dir[2] = dd.z;
-                            rec.weight = dof ? 1.0 / n_dof : (double)a.aadepth;
-                            rec.pixel = (uint32_t)((long long)yl * a.width + x);
-                            rec.obj = id;
-                            want = true;
-                        }
+        for (int aay = 0; aay < n_aay; aay++)
+            for (int ds = 0; ds < n_dof; ds++) {
+                HitRec rec;
+                bool want = false;
+                if (inside) {
+                    rtm::D3 dd = rtm::camera_ray_dir(a.cam_dir, a.cam_right, a.cam_down, a.width, a.height, a.aadepth, x, y, aax);
+                    rtm::D3 org = {a.cam_pos[0], a.cam_pos[1], a.cam_pos[2]}, dj = dd;
+                    if (dof) {                                                           // main.cpp:792-810
+                        rtm::D3 focal = rtm::vadd(org, rtm::vmul(dd, a.focal_len));
+                        rtm::D3 up = {0, 1, 0};
+                        rtm::D3 cam_up = rtm::vadd(up, rtm::vneg(rtm::vmul(dd, rtm::vdot(up, dd))));
+                        rtm::D3 cam_side = rtm::vcross(cam_up, dd);
+                        const uint32_t px = (uint32_t)((long long)y * a.width + x), draw = (uint32_t)(((aay * a.aadepth + aax) * n_dof + ds) * 2);
+                        double jx = -a.aperture + 2 * a.aperture * rtm::counter_uniform(px, draw, a.seed);
+                        double jy = -a.aperture + 2 * a.aperture * rtm::counter_uniform(px, draw + 1u, a.seed);
+                        org = rtm::vadd(rtm::vadd(org, rtm::vmul(cam_up, jx)), rtm::vmul(cam_side, jy));
+                        dj = rtm::vnorm(rtm::vadd(focal, rtm::vneg(org)));
                     }
-                    push_hits(hits, &ctr->hits[1], shard_cap, want, rec, &ovf_queue);
+                    R o[3] = {(R)org.x, (R)org.y, (R)org.z};
+                    R d[3] = {(R)dj.x, (R)dj.y, (R)dj.z};
+                    R dist = R(1e9);
+                    int id = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack);
+                    if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
+                        double t = (double)dist;
+                        // the jittered origin, but the un-jittered direction (main.cpp:821-822)
+                        rec.pos[0] = org.x + dd.x * t; rec.pos[1] = org.y + dd.y * t; rec.pos[2] = org.z + dd.z * t;
+                        rec.dir[0] = dd.x; rec.dir[1] = dd.y; rec.dir[2] = dd.z;
+                        rec.weight = dof ? 1.0 / n_dof : (double)a.aadepth;
+                        rec.pixel = (uint32_t)((long long)yl * a.width + x);
+                        rec.obj = id;
+                        want = true;
+                    }
                 }
+                push_hits(hits, &ctr->hits[1], shard_cap, want, rec, &ovf_queue);
+            }
     }
     if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(0); }
     if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(1); }

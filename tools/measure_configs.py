@@ -108,6 +108,15 @@ def main():
                 rays = st.primary_rays + st.shadow_rays
                 hits = int((buf[0] >= 0).sum().item())
                 print(f"C5 {name} {w}x{h} shadow={shadow}: {rays} rays ({hits} primary hits), kernel {st.trace_kernel_ms:.2f} ms -> {rays / st.trace_kernel_ms / 1e3:.0f} Mrays/s", flush=True)
+        # the full pixel path at 16 samples per pixel (aadepth 4: the reference's pattern has 4 distinct rays, each weighted 4)
+        rgb8 = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+        for prec, name in ((rt.RT_F64, "f64"), (rt.RT_F32, "f32")):
+            p = rt.default_params(width=w, height=h, precision=prec, aadepth=4, use_photon_map=0)
+            for _ in range(2):
+                st = ctx.render_dev(cam, p, (0, h), None, rgb8.data_ptr())
+            print(f"C5 {name} {w}x{h} pixel path, aadepth 4: {st.primary_rays} distinct camera rays (x4 = the reference's 16 per pixel), "
+                  f"device {st.kernel_ms:.1f} ms -> {st.primary_rays / st.kernel_ms / 1e3:.0f} Mrays/s traced, {4 * st.primary_rays / st.kernel_ms / 1e3:.0f} Msamples/s", flush=True)
+        del rgb8
         ref_ids = buf[0].clone()
         t0 = time.perf_counter()
         ms = ctx.upload_lbvh(s)
