@@ -71,6 +71,25 @@ def test_primary_small_sizes_and_row_bands(gpu_ctx, scenes):
         assert eq(ids_b, g["ids"].reshape(h, w)[5:23].ravel())
 
 
+def test_primary_ragged_frames_match_oracle(gpu_ctx, scenes):
+    """Frames whose sides are not multiples of the 8x8 tile or of the 16x8-tile super-blocks the waves walk:
+    every pixel is traced exactly once (ids and t equal to the restatement's, none left at the fill value)."""
+    gpu_ctx.upload(scenes["teapot_normal"])
+    orc = build_scene(Oracle(), "teapot_normal.obj")
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    for (w, h) in [(1, 1), (7, 3), (50, 37), (131, 67), (257, 130)]:
+        p = rt.default_params(width=w, height=h)
+        ids, t, _, st = gpu_ctx.trace_primary(cam, p)
+        org, d = orc.primary_rays(w, h, CAM)
+        oid, ot = orc.shoot(org, d)
+        assert eq(ids, oid), (w, h)
+        assert eq(np.where(ids >= 0, t, 1e9), np.where(oid >= 0, ot, 1e9)), (w, h)
+        assert st.primary_rays == w * h
+        if w >= 50:                                       # the pixel path walks the same tiles (glass: two bounces deep)
+            rgb, _, _ = gpu_ctx.render(cam, rt.default_params(width=w, height=h, use_photon_map=0))
+            assert rgb.shape == (h, w, 3) and np.isfinite(rgb).all()
+
+
 def test_shadow_rays_match_oracle(gpu_ctx, scenes):
     """Occlusion rays (extension) go through the same Shoot semantics with a bounded range."""
     gpu_ctx.upload(scenes["teapot_normal"])
