@@ -92,6 +92,7 @@ struct rt_context {
     int n_objects = 0;
     bool has_scene = false;
     bool has_glossy = false;  // some material takes the 16-sample loops of main.cpp:177-257
+    bool has_bounce = false;  // some material reflects, refracts or scatters below the surface (special != 0): hits can queue rays
     DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
     // photon maps in HBM (0 surface, 1 volume)
     DevBuf ph_pos[2], ph_aux[2], ph_axis[2], ph_order[2], ph_box[2];
@@ -761,9 +762,10 @@ int upload_shading(rt_context* ctx, const rth::Scene& s)
 {
     int rc;
     std::vector<rtf::ObjShade> sh(s.objects.size());
-    ctx->has_glossy = false;
+    ctx->has_glossy = ctx->has_bounce = false;
     for (size_t i = 0; i < sh.size(); i++) {
         sh[i] = s.objects[i].sh;
+        if (sh[i].color[3] != 0.0) ctx->has_bounce = true;
         if (rtm::glossy_special(sh[i].color[3])) ctx->has_glossy = true;
     }
     if ((rc = upload(ctx->objs, sh, ctx->stream))) return rc;
@@ -1285,7 +1287,8 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
 {
     const int rows = a.row_end - a.row_begin;
     const unsigned long long samples = (unsigned long long)a.width * rows * (a.dof_samples > 1 ? a.aadepth * a.aadepth * a.dof_samples : a.aadepth);
-    const int levels = std::min(p->tracing_depth, rtr::MAX_LEVELS);
+    // (a scene of diffuse surfaces only queues no rays: one level, and the deeper launches are not made)
+    const int levels = ctx->has_bounce ? std::min(p->tracing_depth, rtr::MAX_LEVELS) : 1;
     // worst case: every hit of a level spawns two (reflection + refraction); the queues are split into
     // shards of equal capacity that fill nearly evenly (producers pick shards round-robin), with slack
     // (a glossy hit spawns 16 + 16 rays: such scenes are rendered in small row blocks with room for two glossy bounces in a row)
@@ -1363,8 +1366,8 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     a.seed = p->rng_seed;
     a.dof_samples = p->dof_samples; a.focal_len = p->focal_len; a.aperture = p->aperture;
 
-    // row chunks bound the queue memory: at most ~4M distinct camera rays per chunk
-    const long long max_samples = ctx->has_glossy ? 32ll << 10 : 4ll << 20;
+    // row chunks bound the queue memory: at most ~4M distinct camera rays per chunk (16M when no surface can queue a ray)
+    const long long max_samples = ctx->has_glossy ? 32ll << 10 : (ctx->has_bounce ? 4ll << 20 : 16ll << 20);
     const long long per_pixel = p->dof_samples > 1 ? (long long)p->aadepth * p->aadepth * p->dof_samples : p->aadepth;
     int chunk_rows = (int)std::max<long long>(8, (max_samples / ((long long)p->width * per_pixel)) / 8 * 8);
     if ((long long)p->width * chunk_rows >= (1ll << 25)) return fail(RT_ERR_LIMIT, "width %d: a block of 8 rows exceeds 2^25 pixels", p->width);
