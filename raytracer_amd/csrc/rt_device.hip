@@ -1252,14 +1252,14 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
 // the three traversal kernels of the render path for one (R, TRI_ONLY, MODE) choice
 template <class R, bool TRI_ONLY, int MODE>
 int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceGeom& g, int levels, unsigned long long shard_cap,
-                         rtr::RenderCounters* ctr)
+                         rtr::RenderCounters* ctr, double* d_acc)
 {
     const int rows = a.row_end - a.row_begin;
     const int cap = stack_cap(ctx);
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int wpb = g.threads / 64;
     hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE>), dim3((unsigned)rtk::tile_grid_blocks((a.width + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth)), dim3(g.threads), g.lds, ctx->stream,
-                       view<R>(ctx), a, (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes);
+                       view<R>(ctx), a, (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
     HIP_TRY(hipGetLastError());
     // persistent grids for the queue consumers (their work counts live in device memory)
     const int trace_blocks_cu = std::max(1, std::min<int>((int)(160 * 1024 / std::max<size_t>(g.lds, 1)), 12 / wpb));
@@ -1308,17 +1308,16 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     if ((rc = trace_geometry<R>(ctx, ctx->n_nodes, &g))) return rc;
     rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_acc, 0, (size_t)a.width * rows * 3 * sizeof(double), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
     const bool tri_only = view<R>(ctx).tri_only;
     if (tri_only) {
-        if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, true, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr);
-        else if (g.mode == rtk::TRAV_RETEST) rc = launch_render_levels<R, true, rtk::TRAV_RETEST>(ctx, a, g, levels, shard_cap, ctr);
-        else rc = launch_render_levels<R, true, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr);
+        if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, true, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr, d_acc);
+        else if (g.mode == rtk::TRAV_RETEST) rc = launch_render_levels<R, true, rtk::TRAV_RETEST>(ctx, a, g, levels, shard_cap, ctr, d_acc);
+        else rc = launch_render_levels<R, true, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr, d_acc);
     } else {
-        if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, false, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr);
-        else if (g.mode == rtk::TRAV_RETEST) rc = launch_render_levels<R, false, rtk::TRAV_RETEST>(ctx, a, g, levels, shard_cap, ctr);
-        else rc = launch_render_levels<R, false, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr);
+        if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, false, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr, d_acc);
+        else if (g.mode == rtk::TRAV_RETEST) rc = launch_render_levels<R, false, rtk::TRAV_RETEST>(ctx, a, g, levels, shard_cap, ctr, d_acc);
+        else rc = launch_render_levels<R, false, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr, d_acc);
     }
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));

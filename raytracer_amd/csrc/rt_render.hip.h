@@ -111,7 +111,8 @@ __device__ __forceinline__ int rtk_wave_max(int v)
 
 template <class R, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits,
-                                                                       unsigned long long shard_cap, RenderCounters* ctr, int cap, int n_nodes)
+                                                                       unsigned long long shard_cap, RenderCounters* ctr, int cap, int n_nodes,
+                                                                       double* __restrict__ acc)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     const size_t node_bytes = MODE == rtk::TRAV_NODES ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
@@ -129,6 +130,11 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
         bool inside = x < a.width && yl < rows;
         int yc = a.row_begin + yl;
         int y = a.band_rows > 0 ? ((yc / a.band_rows) * a.n_parts + a.part) * a.band_rows + yc % a.band_rows : yc;
+        // the pixel's accumulator starts at zero (the kernels that add to it run after this one): no separate fill pass
+        if (inside && aax == 0) {
+            double* px = acc + ((long long)yl * a.width + x) * 3;
+            px[0] = 0.0; px[1] = 0.0; px[2] = 0.0;
+        }
         // The reference shoots aadepth^2 samples of which only aadepth are distinct (both offsets use
         // aax, main.cpp:775-785): without depth of field each distinct ray is traced once and weighted by
         // its multiplicity.  With it every one of the aadepth^2 x dof_samples rays has its own lens jitter.
