@@ -419,3 +419,41 @@ def test_large_frame_photon_map_against_oracle(gpu_ctx):
     ref, _ = orc.render(w, h, CAM, threads=min(16, os.cpu_count() or 1))
     assert_image_close(rgb, ref, what="C4 960x540")
     assert st.gather_queries > 100000
+
+
+def test_full_size_photon_map_frame(gpu_ctx, monkeypatch):
+    """Configuration C4 at its full size: water surface + Cornell box, 1 M photons emitted, ordered and indexed on the
+    device, k = 1000, 1920x1080.  Two checks that do not need the oracle to render 1.3 M gathers: the grouped gather
+    and the one-request-per-wave gather (different algorithms, same k-nearest sets) give the same frame, and a band
+    of rows through the middle of the frame matches the oracle given the same photon list."""
+    import os
+    rgbs, ior = (0.26, 0.84, 1.0, 1.8), 1.33
+    s = build_scene(rt.Scene(), "water.obj", rgbs, ior)
+    orc = build_scene(Oracle(), "water.obj", rgbs, ior)
+    gpu_ctx.upload(s)
+    n_emit = 1000000
+    (n_surface, n_volume), _ = gpu_ctx.emit_photon_maps(n_emit, seed=12345)
+    assert n_surface > 1000000 and n_volume == 0
+    w, h = 1920, 1080
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    p = rt.default_params(width=w, height=h, photon_num=n_emit, photon_use=1000)
+    rgb, bgr, st = gpu_ctx.render(cam, p)
+    assert st.gather_queries > 1000000 and st.gather_single < st.gather_queries // 4      # most gathers went through groups
+    monkeypatch.setenv("RT_GATHER_MODE", "query")
+    rgb_q, bgr_q, st_q = gpu_ctx.render(cam, p)
+    monkeypatch.delenv("RT_GATHER_MODE")
+    assert st_q.gather_single == st_q.gather_queries == st.gather_queries
+    err = np.abs(rgb - rgb_q).max(axis=-1)
+    # (a request whose k-th and (k+1)-th distances are equal floats may keep the other photon)
+    assert (err < 1e-9).mean() >= 0.999 and err.max() < 2e-3 and (bgr != bgr_q).mean() < 1e-3, ((err < 1e-9).mean(), err.max())
+    ph = gpu_ctx.photon_map_get(0)
+    assert ph.shape == (n_surface, 9)
+    orc.photons_set(np.c_[ph, np.zeros(len(ph))])
+    orc.build_kdtree()
+    orc.params.head_quirk = 0
+    orc.params.photon_num = n_emit
+    orc.params.photon_use = 1000
+    r0, r1 = 536, 544
+    ref, _ = orc.render(w, h, CAM, rows=(r0, r1), threads=min(16, os.cpu_count() or 1))
+    assert_image_close(rgb[r0:r1], ref[r0:r1], what="C4 1920x1080 rows 536..543")
+    assert ref[r0:r1].max() > 0.05
