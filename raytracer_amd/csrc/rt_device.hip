@@ -184,8 +184,8 @@ int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g, int vgpr_wa
     // (TRAV_NODES) when the copy is cheap next to the block's work and leaves room for 3 blocks per CU.
     const int cap = stack_cap(ctx);
     const size_t lds_max = 160 * 1024;
-    // vgpr_waves: waves per CU the register budget of the kernel family admits (12 for the render path's kernels
-    // at up to 168 registers; the primary-ray kernels need about 100 and 75)
+    // vgpr_waves: waves per CU the register budget of the kernel family admits (16 for the render path's kernels,
+    // which are held to 128 registers; 20 for the primary-ray kernels at about 100 and 75)
     int best_w = 0, best_resident = 0, best_mode = rtk::TRAV_PLAIN;
     const char* force = getenv("RT_TRAV_MODE");   // tuning aid: "plain" / "retest"
     for (int mode : {rtk::TRAV_PLAIN, rtk::TRAV_RETEST}) {
@@ -218,7 +218,7 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
 {
     int cap = stack_cap(ctx);
     TraceGeom g;
-    int rc = trace_geometry<R>(ctx, ctx->n_nodes, &g);
+    int rc = trace_geometry<R>(ctx, ctx->n_nodes, &g, 20);
     if (rc) return rc;
     HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
     int wpb = g.threads / 64;
@@ -1258,8 +1258,13 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     const int cap = stack_cap(ctx);
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int wpb = g.threads / 64;
-    hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE>), dim3((unsigned)rtk::tile_grid_blocks((a.width + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth)), dim3(g.threads), g.lds, ctx->stream,
-                       view<R>(ctx), a, (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
+    const dim3 grid((unsigned)rtk::tile_grid_blocks((a.width + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth));
+    if (a.dof_samples > 1)
+        hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE, true>), grid, dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
+                           (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
+    else
+        hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE, false>), grid, dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
+                           (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
     HIP_TRY(hipGetLastError());
     // persistent grids for the queue consumers (their work counts live in device memory)
     const int trace_blocks_cu = std::max(1, std::min<int>((int)(160 * 1024 / std::max<size_t>(g.lds, 1)), 12 / wpb));
@@ -1305,7 +1310,7 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     if ((rc = ctx->gq.reserve(cap_total * sizeof(rtg::GatherRec)))) return rc;
     if ((rc = ctx->redo.reserve(cap_total * sizeof(uint32_t)))) return rc;
     TraceGeom g;
-    if ((rc = trace_geometry<R>(ctx, ctx->n_nodes, &g))) return rc;
+    if ((rc = trace_geometry<R>(ctx, ctx->n_nodes, &g, 16))) return rc;
     rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));

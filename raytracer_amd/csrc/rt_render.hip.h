@@ -109,7 +109,9 @@ __device__ __forceinline__ int rtk_wave_max(int v)
     return v;
 }
 
-template <class R, bool TRI_ONLY, int MODE>
+// DOF (depth of field compiled in) is a template parameter: its sample loops around the traversal cost the kernel 60
+// registers (147 instead of 87 in f64), and the reference's default build has no depth of field (main.cpp:35).
+template <class R, bool TRI_ONLY, int MODE, bool DOF>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits,
                                                                        unsigned long long shard_cap, RenderCounters* ctr, int cap, int n_nodes,
                                                                        double* __restrict__ acc)
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
         // The reference shoots aadepth^2 samples of which only aadepth are distinct (both offsets use
         // aax, main.cpp:775-785): without depth of field each distinct ray is traced once and weighted by
         // its multiplicity.  With it every one of the aadepth^2 x dof_samples rays has its own lens jitter.
-        const bool dof = a.dof_samples > 1;
+        const bool dof = DOF;
         const int n_aay = dof ? a.aadepth : 1, n_dof = dof ? a.dof_samples : 1;
         for (int aay = 0; aay < n_aay; aay++)
             for (int ds = 0; ds < n_dof; ds++) {
@@ -356,6 +358,8 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
 }
 
 // Shoot for every queued ray of a level; hits become the next level's queue (main.cpp:190-199, 242-250).
+// (The draw loop around the traversal costs this kernel about 45 registers -- 144 instead of 100 in f64, three waves per
+// SIMD.  Holding it to 128 with amdgpu_waves_per_eu spills 12 of them and was measured slower on both test frames.)
 template <class R, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneView<R> sv, RenderArgs a, int level, const RayRec* __restrict__ rays,
                                                                     HitRec* __restrict__ out, unsigned long long shard_cap, RenderCounters* ctr,
