@@ -90,6 +90,23 @@ def test_primary_ragged_frames_match_oracle(gpu_ctx, scenes):
             assert rgb.shape == (h, w, 3) and np.isfinite(rgb).all()
 
 
+@pytest.mark.parametrize("n_parts", [2, 4, 8])
+def test_primary_row_bands_of_all_parts_make_the_frame(gpu_ctx, scenes, n_parts):
+    """The multi-GPU split of the primary-ray path: every part traces its bands of 8 rows into a compact buffer;
+    de-interleaved, the parts are the frame one GPU traces alone (ids, t and shadow ids)."""
+    from raytracer_amd import tiling
+    gpu_ctx.upload(scenes["teapot_normal"])
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    w, h = 200, tiling.BAND * n_parts * 3
+    whole = gpu_ctx.trace_primary(cam, rt.default_params(width=w, height=h, shadow_rays=1))
+    parts = [gpu_ctx.trace_primary(cam, rt.default_params(width=w, height=h, shadow_rays=1, band_rows=tiling.BAND, n_parts=n_parts, part=r))
+             for r in range(n_parts)]
+    for k in range(3):
+        got = tiling.deinterleave([pt[k].reshape(h // n_parts, w) for pt in parts])
+        assert eq(got.ravel(), whole[k]), (n_parts, k)
+    assert sum(pt[3].shadow_rays for pt in parts) == whole[3].shadow_rays
+
+
 def test_shadow_rays_match_oracle(gpu_ctx, scenes):
     """Occlusion rays (extension) go through the same Shoot semantics with a bounded range."""
     gpu_ctx.upload(scenes["teapot_normal"])
