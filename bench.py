@@ -55,8 +55,10 @@ def main():
     from raytracer_amd import tiling
     BAND = tiling.BAND
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one GPU per rank: its index is the local rank, or 0 when the launcher shows each rank only its own device
+    dev_index = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
@@ -65,7 +67,7 @@ def main():
     scene.load_obj(os.path.join(DATA, args.mesh))
     scene.add_cornell()
     scene.build_bvh()
-    ctx = rt.Context(local_rank)
+    ctx = rt.Context(dev_index)
     ctx.upload(scene)
     cam = rt.look_at(CAM[:3], CAM[3:])
 
