@@ -251,7 +251,18 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
 int rt_render_rows(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end,
                    double* rgb, uint8_t* bgr8, rt_stats* stats);
 
+/* ---- device: several GPUs in one process ------------------------------------------------- */
+/* Frame assembly over the GPUs of ONE process.  The reference's threads write column strips of one host frame
+ * (main.cpp:735-861); here part r of n_parts (rt_render_params.band_rows / n_parts / part) is traced by ctxs[r] into
+ * the compact device buffer d_parts[r] (height / n_parts rows of row_bytes), and this call copies every band to its
+ * place in d_frame (height rows of row_bytes, on the device of ctxs[0]): one strided device-to-device copy per part,
+ * enqueued behind that part's kernels, direct over xGMI where the devices can reach each other.  Returns when the frame
+ * is complete.  (Processes with one GPU each gather over RCCL instead, see raytracer_amd/tiling.py.) */
+int rt_gather_rows(rt_context* const* ctxs, const void* const* d_parts, int n_parts, int band_rows, int height, size_t row_bytes,
+                   void* d_frame);
+
 /* ---- host I/O either side of the path ---------------------------------------------------- */
+
 /* saveBmp(filename, w, h, dpi, data), IO.cpp:5: byte-identical file (header quirks included) */
 int rt_save_bmp(const char* path, int w, int h, int dpi, const double* rgb);
 int rt_save_bmp_bgr8(const char* path, int w, int h, int dpi, const uint8_t* bgr);

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import RT_F32, RT_F64, Camera, RenderParams, Stats, lib
 
-__all__ = ["Scene", "Context", "RtError", "RT_F32", "RT_F64", "default_params", "look_at", "save_bmp"]
+__all__ = ["Scene", "Context", "RtError", "RT_F32", "RT_F64", "default_params", "look_at", "save_bmp", "gather_rows"]
 
 
 class RtError(RuntimeError):
@@ -302,6 +302,15 @@ Context.knn_estimate = _ctx_knn_estimate
 Context.knn_estimate_grouped = _ctx_knn_estimate_grouped
 Context.render = _ctx_render
 Context.render_dev = _ctx_render_dev
+
+
+def gather_rows(ctxs, d_parts, band_rows, height, row_bytes, d_frame):
+    """rt_gather_rows: the compact band buffers d_parts[r] (device pointers, traced by ctxs[r]) -> the frame d_frame on
+    the device of ctxs[0]."""
+    n = len(ctxs)
+    hs = (_lib.vp * n)(*[c.h for c in ctxs])
+    ps = (_lib.vp * n)(*[ctypes.c_void_p(int(p) if not isinstance(p, ctypes.c_void_p) else p.value) for p in d_parts])
+    _chk(lib.rt_gather_rows(hs, ps, n, band_rows, height, row_bytes, d_frame), "rt_gather_rows")
 
 
 def save_bmp(path, rgb, dpi=72):

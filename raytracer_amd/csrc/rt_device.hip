@@ -1442,6 +1442,44 @@ int rt_render_rows(rt_context* ctx, const rt_camera* cam, const rt_render_params
     return RT_OK;
 }
 
+// ---------------------------------------------------------------- frame assembly over the GPUs of one process
+int rt_gather_rows(rt_context* const* ctxs, const void* const* d_parts, int n_parts, int band_rows, int height, size_t row_bytes, void* d_frame)
+{
+    if (!ctxs || !d_parts || !d_frame || n_parts < 1 || band_rows < 1 || height < 1 || row_bytes == 0) return fail(RT_ERR_INVALID, "bad argument");
+    if (height % (band_rows * n_parts) != 0)
+        return fail(RT_ERR_INVALID, "row interleave band_rows %d n_parts %d does not tile height %d", band_rows, n_parts, height);
+    for (int r = 0; r < n_parts; r++)
+        if (!ctxs[r] || !d_parts[r]) return fail(RT_ERR_INVALID, "part %d: null context or buffer", r);
+    const int dst_device = ctxs[0]->device;
+    const size_t band_bytes = (size_t)band_rows * row_bytes;
+    const size_t n_bands = (size_t)height / ((size_t)band_rows * n_parts);        // per part
+    for (int r = 0; r < n_parts; r++) {
+        rt_context* c = ctxs[r];
+        int rc = use_device(c);
+        if (rc) return rc;
+        if (c->device != dst_device) {
+            // direct xGMI copies where the devices can reach each other; the runtime stages the copy otherwise
+            int can = 0;
+            HIP_TRY(hipDeviceCanAccessPeer(&can, c->device, dst_device));
+            if (can) {
+                hipError_t e = hipDeviceEnablePeerAccess(dst_device, 0);
+                if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                else if (e != hipSuccess) return fail(RT_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s", c->device, dst_device, hipGetErrorString(e));
+            }
+        }
+        // band b of part r is band b * n_parts + r of the frame: one strided copy per part, in the order of the
+        // stream that traced the part
+        HIP_TRY(hipMemcpy2DAsync((char*)d_frame + (size_t)r * band_bytes, band_bytes * n_parts, d_parts[r], band_bytes, band_bytes, n_bands, hipMemcpyDefault,
+                                 c->stream));
+    }
+    for (int r = 0; r < n_parts; r++) {
+        int rc = use_device(ctxs[r]);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(ctxs[r]->stream));
+    }
+    return use_device(ctxs[0]);
+}
+
 // ---------------------------------------------------------------- host I/O
 int rt_save_bmp(const char* path, int w, int h, int dpi, const double* rgb)
 {

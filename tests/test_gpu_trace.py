@@ -107,6 +107,40 @@ def test_primary_row_bands_of_all_parts_make_the_frame(gpu_ctx, scenes, n_parts)
     assert sum(pt[3].shadow_rays for pt in parts) == whole[3].shadow_rays
 
 
+def test_gather_rows_assembles_the_frame_on_the_device(scenes):
+    """rt_gather_rows (several GPUs in one process): three contexts -- on a one-GPU box all on device 0 -- trace their
+    bands into compact device buffers; the strided device copies put every band in its place in the frame."""
+    import ctypes
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")                    # the runtime the library itself uses
+    n_parts, band = 3, 8
+    w, h = 200, band * n_parts * 4
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    ctxs = [rt.Context(0) for _ in range(n_parts)]
+    for c in ctxs:
+        c.upload(scenes["teapot_normal"])
+    whole, _, _, _ = ctxs[0].trace_primary(cam, rt.default_params(width=w, height=h, shadow_rays=0))
+
+    def dmalloc(n_bytes):
+        p = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n_bytes)) == 0
+        return p
+    part_bytes = (h // n_parts) * w * 4
+    d_parts = [dmalloc(part_bytes) for _ in range(n_parts)]
+    d_frame = dmalloc(h * w * 4)
+    assert hip.hipMemset(d_frame, 0xFF, ctypes.c_size_t(h * w * 4)) == 0
+    for r, c in enumerate(ctxs):
+        p = rt.default_params(width=w, height=h, shadow_rays=0, band_rows=band, n_parts=n_parts, part=r)
+        c.trace_primary_dev(cam, p, (0, h // n_parts), d_parts[r], None, None, stats=False)      # enqueued, not waited for
+    rt.gather_rows(ctxs, d_parts, band, h, w * 4, d_frame)
+    got = np.zeros(h * w, np.int32)
+    assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), d_frame, ctypes.c_size_t(h * w * 4), 2) == 0
+    for p in d_parts + [d_frame]:
+        assert hip.hipFree(p) == 0
+    assert eq(got, whole)
+    with pytest.raises(rt.RtError):
+        rt.gather_rows(ctxs, d_parts, band, h + 1, w * 4, d_frame)          # does not tile: refused before any copy
+
+
 def test_shadow_rays_match_oracle(gpu_ctx, scenes):
     """Occlusion rays (extension) go through the same Shoot semantics with a bounded range."""
     gpu_ctx.upload(scenes["teapot_normal"])
