@@ -28,12 +28,13 @@ public:
         SceneSink sink;
         sink.scene = scene;
         for (Object* o : objects) rt::check(o->describe(sink), "Object::describe");
+        // (the scene is replicated on every GPU of rt::devices())
         if (device_build) {
-            rt::check(rt_scene_upload_lbvh(rt::device(), scene, nullptr), "rt_scene_upload_lbvh");
+            for (rt_context* ctx : rt::devices()) rt::check(rt_scene_upload_lbvh(ctx, scene, nullptr), "rt_scene_upload_lbvh");
             return;
         }
         host_tree();
-        rt::check(rt_scene_upload(rt::device(), scene), "rt_scene_upload");
+        for (rt_context* ctx : rt::devices()) rt::check(rt_scene_upload(ctx, scene), "rt_scene_upload");
     }
     ~BVH() { rt_scene_destroy(scene); }
     BVH(const BVH&) = delete;

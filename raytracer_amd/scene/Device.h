@@ -1,8 +1,9 @@
-// Process-wide GPU context used by the scene classes (BVH, KDTree, Renderer).  The device index
-// comes from RT_DEVICE (default 0).  Failing to get a gfx950 device is fatal: there is no CPU path.
+// Process-wide GPU contexts used by the scene classes (BVH, KDTree, Renderer): one per GPU named by
+// RT_DEVICES (default: the one RT_DEVICE names, else 0).  Failing to get a gfx950 device is fatal: there is no CPU path.
 #pragma once
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "../../include/rt_amd.h"
 
@@ -16,14 +17,36 @@ inline void check(int status, const char* what)
     }
 }
 
-inline rt_context* device()
+// RT_DEVICES=0,1,2,...: the GPUs the scene is replicated on and the pixel loop is split over (the reference splits
+// it over host threads, main.cpp:689-695); default: the single device RT_DEVICE names (0).
+inline std::vector<rt_context*>& devices()
 {
-    static rt_context* ctx = nullptr;
-    if (!ctx) {
-        const char* env = getenv("RT_DEVICE");
-        check(rt_context_create(env ? atoi(env) : 0, &ctx), "rt_context_create");
+    static std::vector<rt_context*> ctxs;
+    if (ctxs.empty()) {
+        std::vector<int> ids;
+        if (const char* list = getenv("RT_DEVICES")) {
+            for (const char* p = list; *p;) {
+                char* end = nullptr;
+                long v = strtol(p, &end, 10);
+                if (end == p) break;
+                ids.push_back((int)v);
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
+        if (ids.empty()) {
+            const char* env = getenv("RT_DEVICE");
+            ids.push_back(env ? atoi(env) : 0);
+        }
+        for (int id : ids) {
+            rt_context* c = nullptr;
+            check(rt_context_create(id, &c), "rt_context_create");
+            ctxs.push_back(c);
+        }
     }
-    return ctx;
+    return ctxs;
 }
+
+// the first of them: single-ray and batch queries go here
+inline rt_context* device() { return devices()[0]; }
 
 }  // namespace rt

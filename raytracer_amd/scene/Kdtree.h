@@ -34,10 +34,12 @@ public:
             for (int c = 0; c < 3; c++) { f[c] = p->position[c]; f[6 + c] = p->dir[c]; }
             f[3] = p->power.getColorRed(); f[4] = p->power.getColorGreen(); f[5] = p->power.getColorBlue();
         }
-        if (device_build)
-            rt::check(rt_photons_upload_dev_build(rt::device(), which, (int64_t)photons.size(), flat.data()), "rt_photons_upload_dev_build");
-        else
-            rt::check(rt_photons_upload(rt::device(), which, (int64_t)photons.size(), flat.data()), "rt_photons_upload");
+        for (rt_context* ctx : rt::devices()) {       // the photon map is replicated like the scene
+            if (device_build)
+                rt::check(rt_photons_upload_dev_build(ctx, which, (int64_t)photons.size(), flat.data()), "rt_photons_upload_dev_build");
+            else
+                rt::check(rt_photons_upload(ctx, which, (int64_t)photons.size(), flat.data()), "rt_photons_upload");
+        }
     }
 
     std::vector<Photon*> findKNN(int k, Vect center) const

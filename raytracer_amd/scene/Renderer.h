@@ -2,6 +2,9 @@
 // (main.cpp:683-720) and the per-pixel ray-trace loop (main.cpp:735-863).  Emission stays on the
 // host (it is RNG-order dependent); the pixel loop runs on the GPU through rt_render_rows.
 #pragma once
+#include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "BVH.h"
@@ -52,17 +55,67 @@ public:
                              long long* volume_count = nullptr)
     {
         int64_t counts[2] = {0, 0};
-        rt::check(rt_emit_photon_maps_dev(rt::device(), n_emit, light_position.data(), seed, bounce, accuracy, counts, nullptr), "rt_emit_photon_maps_dev");
+        // every GPU emits for itself: the streams are keyed by seed and photon number, so the maps are identical
+        for (rt_context* ctx : rt::devices())
+            rt::check(rt_emit_photon_maps_dev(ctx, n_emit, light_position.data(), seed, bounce, accuracy, counts, nullptr), "rt_emit_photon_maps_dev");
         if (volume_count) *volume_count = counts[1];
         return counts[0];
     }
 
-    // the pixel loop: pixels[y * width + x], y = 0 is the bottom BMP row (main.cpp:739,758)
+    // the pixel loop: pixels[y * width + x], y = 0 is the bottom BMP row (main.cpp:739,758).  With several GPUs
+    // (RT_DEVICES) one host thread drives each -- the reference's thread fan-out, main.cpp:689-695,735-736 -- over
+    // bands of 8 rows dealt round-robin (cost is uneven over the frame), or contiguous row blocks when the height does
+    // not divide into such bands.
     rt_stats render(const Camera& cam, const rt_render_params& params, RGBType* pixels)
     {
         rt_camera c = cam.abi();
+        const std::vector<rt_context*>& ctxs = rt::devices();
+        const int n = (int)ctxs.size(), w = params.width, h = params.height;
         rt_stats st;
-        rt::check(rt_render_rows(rt::device(), &c, &params, 0, params.height, &pixels[0].r, nullptr, &st), "rt_render_rows");
+        if (n == 1) {
+            rt::check(rt_render_rows(ctxs[0], &c, &params, 0, h, &pixels[0].r, nullptr, &st), "rt_render_rows");
+            return st;
+        }
+        const int band = 8;
+        const bool bands = h % (band * n) == 0;
+        std::vector<rt_stats> part_st((size_t)n);
+        std::vector<int> status((size_t)n, 0);
+        std::vector<std::string> message((size_t)n);
+        std::vector<std::vector<double>> part(bands ? (size_t)n : 0);
+        std::vector<std::thread> threads;
+        for (int r = 0; r < n; r++)
+            threads.emplace_back([&, r]() {
+                rt_render_params p = params;
+                memset(&part_st[(size_t)r], 0, sizeof(rt_stats));
+                if (bands) {
+                    p.band_rows = band; p.n_parts = n; p.part = r;
+                    part[(size_t)r].resize((size_t)w * (size_t)(h / n) * 3);
+                    status[(size_t)r] = rt_render_rows(ctxs[(size_t)r], &c, &p, 0, h / n, part[(size_t)r].data(), nullptr, &part_st[(size_t)r]);
+                } else {
+                    const int r0 = (int)((long long)h * r / n), r1 = (int)((long long)h * (r + 1) / n);
+                    if (r1 > r0) status[(size_t)r] = rt_render_rows(ctxs[(size_t)r], &c, &p, r0, r1, &pixels[(size_t)r0 * (size_t)w].r, nullptr, &part_st[(size_t)r]);
+                }
+                if (status[(size_t)r] < 0) message[(size_t)r] = rt_last_error();      // (the message is per thread)
+            });
+        for (std::thread& t : threads) t.join();
+        for (int r = 0; r < n; r++)
+            if (status[(size_t)r] < 0) {
+                fprintf(stderr, "raytracer_amd: rt_render_rows on GPU %d of %d failed (%d): %s\n", r, n, status[(size_t)r], message[(size_t)r].c_str());
+                abort();
+            }
+        if (bands)
+            for (int r = 0; r < n; r++)
+                for (int yc = 0; yc < h / n; yc++) {
+                    const int y = ((yc / band) * n + r) * band + yc % band;
+                    memcpy(&pixels[(size_t)y * (size_t)w].r, &part[(size_t)r][(size_t)yc * (size_t)w * 3], (size_t)w * 3 * sizeof(double));
+                }
+        memset(&st, 0, sizeof st);
+        for (const rt_stats& s : part_st) {
+            st.primary_rays += s.primary_rays; st.secondary_rays += s.secondary_rays; st.shadow_rays += s.shadow_rays;
+            st.gather_queries += s.gather_queries; st.gather_single += s.gather_single;
+            st.kernel_ms = s.kernel_ms > st.kernel_ms ? s.kernel_ms : st.kernel_ms;
+            st.trace_kernel_ms = s.trace_kernel_ms > st.trace_kernel_ms ? s.trace_kernel_ms : st.trace_kernel_ms;
+        }
         return st;
     }
 };

@@ -42,3 +42,22 @@ def test_main_style_scene_program(tmp_path, device_tree):
     # rays that start on a box face (a triangle's own vertices span its leaf's box), which an exhaustive
     # search finds.  A few glass pixels therefore differ and the bar for that tree is 99 %.
     assert within >= (0.99 if device_tree else 0.999), within
+
+
+@pytest.mark.parametrize("devices", ["0,0,0", "0,0"])
+def test_scene_program_split_over_several_contexts(tmp_path, devices):
+    """RT_DEVICES: the scene classes replicate the scene and the photon map on every listed GPU and the Renderer
+    drives one host thread per GPU (a one-GPU box lists device 0 several times): bands of 8 rows when the height
+    divides into them (72 rows over 3), contiguous row blocks otherwise (72 rows over 2).  Same BMP, byte for byte."""
+    exe = os.path.join(ROOT, "examples", "main_scene")
+    assert os.path.exists(exe), "examples/main_scene missing: run __graft_entry__.build()"
+    w, h, nph, seed = 96, 72, 3000, 12345
+    outs = []
+    for tag, env in (("one", {}), ("many", {"RT_DEVICES": devices})):
+        out = str(tmp_path / f"scene_{tag}.bmp")
+        r = subprocess.run([exe, os.path.join(DATA, "teapot_normal.obj"), out, str(w), str(h), str(nph), str(seed), "1.8", "1.5", "-0.7"],
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout
+        outs.append(np.fromfile(out, np.uint8))
+    assert len(outs[0]) == 54 + w * h * 3 and outs[0][54:].max() > 0
+    assert np.array_equal(outs[0], outs[1])
