@@ -160,8 +160,8 @@ def main():
     alg_bytes = st_work.inner_visits * node_b + st_work.prim_tests * prim_b
     rank_rays = st_work.primary_rays + st_work.shadow_rays
     # average launch duration: HIP events on the library's stream around the K timed launches, / K
-    # (includes the 64-byte counter clear that precedes each launch); the library's own event pair
-    # around a single launch is reported next to it
+    # (back-to-back launches, nothing else on the stream); the library's own event pair around a
+    # single launch is reported next to it
     avg_kernel_ms = head_dev_ms
     single_kernel_ms = st_work_plain.trace_kernel_ms
     achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9

@@ -214,13 +214,14 @@ int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g, int vgpr_wa
 }
 
 template <class R, bool COUNT, bool TRI_ONLY>
-int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow)
+int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow, bool want_counts)
 {
     int cap = stack_cap(ctx);
     TraceGeom g;
     int rc = trace_geometry<R>(ctx, ctx->n_nodes, &g, 20);
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
+    // the per-call counters are cleared only for a caller that reads them (an overflow is latched on the device either way)
+    if (want_counts) HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
     int wpb = g.threads / 64;
     int blocks = (int)rtk::tile_grid_blocks((a.width + 7) / 8, (a.row_end - a.row_begin + 7) / 8, wpb, g.mode == rtk::TRAV_NODES);
 #define RT_LAUNCH_PRIMARY(MODE)                                                                                                              \
@@ -235,10 +236,10 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
 }
 
 template <class R, bool COUNT>
-int launch_primary(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow)
+int launch_primary(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow, bool want_counts)
 {
-    return view<R>(ctx).tri_only ? launch_primary_t<R, COUNT, true>(ctx, a, d_ids, d_t, d_shadow)
-                                 : launch_primary_t<R, COUNT, false>(ctx, a, d_ids, d_t, d_shadow);
+    return view<R>(ctx).tri_only ? launch_primary_t<R, COUNT, true>(ctx, a, d_ids, d_t, d_shadow, want_counts)
+                                 : launch_primary_t<R, COUNT, false>(ctx, a, d_ids, d_t, d_shadow, want_counts);
 }
 
 int check_params(const rt_render_params* p)
@@ -1011,9 +1012,9 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
     a.band_rows = p->band_rows; a.n_parts = p->n_parts; a.part = p->part;
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     if (p->count_work)
-        rc = p->precision == RT_F64 ? launch_primary<double, true>(ctx, a, d_ids, d_t, d_shadow_ids) : launch_primary<float, true>(ctx, a, d_ids, d_t, d_shadow_ids);
+        rc = p->precision == RT_F64 ? launch_primary<double, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr) : launch_primary<float, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr);
     else
-        rc = p->precision == RT_F64 ? launch_primary<double, false>(ctx, a, d_ids, d_t, d_shadow_ids) : launch_primary<float, false>(ctx, a, d_ids, d_t, d_shadow_ids);
+        rc = p->precision == RT_F64 ? launch_primary<double, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr) : launch_primary<float, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (stats) {
