@@ -1010,13 +1010,13 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
     a.width = p->width; a.height = p->height; a.row_begin = row_begin; a.row_end = row_end;
     a.shadow = p->shadow_rays ? 1 : 0;
     a.band_rows = p->band_rows; a.n_parts = p->n_parts; a.part = p->part;
-    HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+    if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));      // (timing events only for a caller that reads them)
     if (p->count_work)
         rc = p->precision == RT_F64 ? launch_primary<double, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr) : launch_primary<float, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr);
     else
         rc = p->precision == RT_F64 ? launch_primary<double, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr) : launch_primary<float, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (stats) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (stats) {
         rtk::TraceCounters c;
         if ((rc = read_counters(ctx, &c))) return rc;
