@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--mesh", default="teapot_normal.obj")
     ap.add_argument("--no-cpu-baseline", action="store_true")
