@@ -355,6 +355,27 @@ class Reference(_Common):
     def save_bmp(self, path, w, h, rgb, dpi=72):
         self.lib.ref_save_bmp(path.encode(), ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(dpi), _dp(_f64(rgb)))
 
+    def color_intended(self, pos, d, obj, depth=1):
+        """The shade loop recursing on the newly hit object, driven through the reference's own functions."""
+        pos = _f64(pos); d = _f64(d); obj = _i32(obj); out = np.zeros((len(obj), 3))
+        self.lib.ref_color_intended(c_l(len(obj)), _dp(pos), _dp(d), _ip(obj), ctypes.c_int(depth), _dp(out))
+        return out
+
+    def primary_rays_aa(self, w, h, aadepth, cam):
+        org = np.zeros((w * h * aadepth, 3)); d = np.zeros((w * h * aadepth, 3))
+        self.lib.ref_primary_rays_aa(ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(aadepth), _dp(_f64(cam)), _dp(org), _dp(d))
+        return org, d
+
+    def render(self, w, h, cam, aadepth=1, intended=True):
+        rgb = np.zeros((h, w, 3))
+        self.lib.ref_render(ctypes.c_int(w), ctypes.c_int(h), ctypes.c_int(aadepth), _dp(_f64(cam)), ctypes.c_int(int(intended)), _dp(rgb))
+        return rgb
+
+    def load_obj_no_normals(self, path, rgbs=(0.5, 0.5, 0.5, 0.0), ior=1.0, off=(0, 0, 0), use_texture=False, map_idx=-1):
+        """Meshes whose faces have no normal index (the reference's own reader crashes on them)."""
+        return self.lib.ref_scene_load_obj_no_normals(path.encode(), c_d(rgbs[0]), c_d(rgbs[1]), c_d(rgbs[2]), c_d(rgbs[3]), c_f(ior),
+                                                      c_f(off[0]), c_f(off[1]), c_f(off[2]), ctypes.c_int(int(use_texture)), ctypes.c_int(map_idx))
+
 
 def id_map_hash(ids):
     """FNV-style hash of a hit-ID map: h = (h ^ uint32(id + 1)) * 1099511628211 mod 2^64."""

@@ -324,6 +324,145 @@ def main():
     np.savez_compressed(os.path.join(GOLD, "glossy_head_64.npz"), pos=pos, dir=d[sel], ids=ids[sel].astype(np.int32), rgb=rcol,
                         photons=surf, volume_photons=vol)
 
+
+
+def tex_spheres_scene(api, tex):
+    """Textured smooth-normal triangles + the reference's mirror and glass spheres (main.cpp:623-668) in the box."""
+    r2 = np.random.default_rng(5)
+    for i in range(30):
+        c = r2.uniform(-0.7, 0.7, 3)
+        A, C, B = c + r2.uniform(-0.35, 0.35, (3, 3))
+        api.add_triangle(A, C, B, (0.8, 0.7, 0.6, 0.0), 1.3)
+        nn = r2.normal(size=(3, 3)); nn /= np.linalg.norm(nn, axis=1)[:, None]
+        tt = r2.uniform(-1, 2, (3, 2))
+        api.last_set_normals(nn[0], nn[1], nn[2]); api.last_set_texture(tt[0], tt[1], tt[2], True, tex)
+    api.add_sphere((0.3, -0.4, -0.4), 0.3, (1.0, 1.0, 1.0, 0.9), 1.5)
+    api.add_sphere((0.3, -0.7, 0.4), 0.3, (1.0, 1.0, 1.0, 1.8), 1.5)
+    api.add_cornell()
+    api.build_bvh()
+
+
+def intended_mode():
+    """G10: the recursion on the newly hit object (the product's default), produced by the reference's own
+    Shoot / getColor / getNormalAt / computeReflectionDir / computeGlossyRay / getColorAt driven by
+    ref_harness.cpp's shade_intended, and the restatement's head_quirk = 0 mode checked against it bit for bit."""
+    for tag, mesh, rgbs, ior, off in [("mirror", "teapot_normal.obj", (1.0, 1.0, 1.0, 0.9), 1.5, (0, -0.7, 0)),
+                                      ("glass", "teapot_normal.obj", (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0)),
+                                      ("water", "water.obj", (0.26, 0.84, 1.0, 1.8), 1.33, (0, 0, 0))]:
+        ref = Reference(); orc = Oracle()
+        build_scene(ref, mesh, rgbs, ior, off); build_scene(orc, mesh, rgbs, ior, off)
+        ref.seed(12345); orc.seed(12345)
+        ref.emit_photons(3000); orc.emit_photons(3000)
+        ref.build_kdtree(); orc.build_kdtree()
+        w = h = 64
+        rgb = ref.render(w, h, CAM, intended=True)
+        head = ref.render(w, h, CAM, intended=False)
+        orc.params.head_quirk = 0
+        orgb, _ = orc.render(w, h, CAM, threads=4)
+        check(f"render 64x64 {tag} (recursion on the new hit)", rgb, orgb)
+        lit = int((np.abs(rgb - head).max(-1) > 1e-3).sum())
+        print(f"     {lit} of {w * h} pixels differ from the HEAD-semantics frame")
+        np.savez_compressed(os.path.join(GOLD, f"render_{tag}_intended_64.npz"), rgb=rgb, photons=ref.photons_get()[:, :9],
+                            rgbs=np.array(rgbs), ior=ior, off=np.array(off, dtype=np.float64))
+
+    # textured smooth-normal triangles + mirror and glass spheres, with and without the AA sample pattern
+    tex = os.path.join(DATA, "tex.bmp")
+    ref = Reference(); orc = Oracle()
+    tex_spheres_scene(ref, ref.texture_read(tex)); tex_spheres_scene(orc, orc.texture_read(tex))
+    ref.seed(3); orc.seed(3)
+    nr = ref.emit_photons(3000); no = orc.emit_photons(3000)
+    check(f"photon count textured scene ({nr})", nr, no)
+    ref.build_kdtree(); orc.build_kdtree()
+    orc.params.head_quirk = 0
+    gold = dict(photons=ref.photons_get()[:, :9])
+    for (w, h, aa) in [(96, 72, 1), (80, 60, 2), (80, 60, 4)]:
+        ro, rd = ref.primary_rays_aa(w, h, aa, CAM); oo, od = orc.primary_rays_aa(w, h, aa, CAM)
+        check(f"camera rays {w}x{h} aadepth {aa}", rd, od)
+        rgb = ref.render(w, h, CAM, aadepth=aa, intended=True)
+        orgb, _ = orc.render(w, h, CAM, aadepth=aa, threads=4)
+        check(f"render textured + spheres {w}x{h} aadepth {aa} (recursion on the new hit)", rgb, orgb)
+        gold[f"rgb_{w}x{h}_aa{aa}"] = rgb
+    np.savez_compressed(os.path.join(GOLD, "render_texspheres_intended.npz"), **gold)
+
+    # glossy balls in intended mode: 16 + 16 jittered rays per hit from the shared mt19937; a small photon map keeps
+    # the 16^3 .. 32^3 leaf gathers per pixel cheap.  Hits on the balls only, in one fixed order.
+    ref = Reference(); orc = Oracle()
+    for api in (ref, orc):
+        api.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0, -0.7, 0))
+        api.add_sphere((0.0, 0.35, 0.55), 0.3, (1.0, 1.0, 1.0, 0.987654), 1.0)
+        api.add_sphere((0.0, 0.35, -0.55), 0.3, (1.0, 1.0, 1.0, 1.887654), 1.5)
+        api.add_cornell()
+        api.build_bvh()
+        api.seed(4242)
+    ref.emit_photons(400); orc.emit_photons(400)
+    surf = ref.photons_get(0)[:, :9].copy()
+    ref.build_kdtree(); orc.build_kdtree()
+    org, d = ref.primary_rays(64, 64, CAM)
+    ids, t = ref.shoot(org, d)
+    hit = np.flatnonzero((ids >= 0) & (t > 1e-6))
+    mirror, glass = hit[ids[hit] == 992], hit[ids[hit] == 993]
+    sel = np.concatenate([mirror[::40], glass[::80]])
+    pos = org[sel] + d[sel] * t[sel][:, None]
+    ref.seed(99); orc.seed(99)
+    orc.params.head_quirk = 0
+    rcol = ref.color_intended(pos, d[sel], ids[sel], 1); ocol = orc.get_color_at(pos, d[sel], ids[sel], 1)
+    check(f"glossy balls, recursion on the new hit, same mt19937 sequence ({len(sel)} hits)", rcol, ocol)
+    print("     brightest glossy sample", rcol.max())
+    np.savez_compressed(os.path.join(GOLD, "glossy_intended.npz"), pos=pos, dir=d[sel], ids=ids[sel].astype(np.int32), rgb=rcol, photons=surf)
+
+
+def meshes_without_normals():
+    """G11: teapot1.obj (`f v/vt`) and test.obj: flat-normal triangles built by the harness's own reader (the
+    reference's crashes on such faces), traced and shaded by the reference; the restatement's tolerant loader must
+    produce the same scene."""
+    hashes = {}
+    rng = np.random.default_rng(777)
+    for mesh in ["teapot1.obj", "test.obj"]:
+        tag = mesh.split(".")[0]
+        ref = Reference(); orc = Oracle()
+        assert ref.load_obj_no_normals(os.path.join(DATA, mesh)) == 1
+        assert orc.load_obj(os.path.join(DATA, mesh)) == 1
+        for api in (ref, orc):
+            api.add_cornell(); api.build_bvh()
+        check(f"scene size {tag} ({ref.size()})", ref.size(), orc.size())
+        r_rec, r_box = ref.bvh_dump(); o_rec, o_box = orc.bvh_dump()
+        check(f"bvh topology {tag}", r_rec, o_rec)
+        check(f"bvh boxes {tag}", r_box, o_box)
+        w, h = 1920, 1080
+        r_org, r_dir = ref.primary_rays(w, h, CAM)
+        r_ids, r_t = ref.shoot(r_org, r_dir); o_ids, o_t = orc.shoot_mt(r_org, r_dir)
+        check(f"hit ids 1920x1080 {tag}", r_ids, o_ids)
+        check(f"hit t 1920x1080 {tag}", r_t, o_t)
+        nmesh = ref.size() - 10
+        hashes[tag] = dict(hash=id_map_hash(r_ids), hits=int((r_ids >= 0).sum()), mesh_hits=int(((r_ids >= 0) & (r_ids < nmesh)).sum()),
+                           t_sha256=hashlib.sha256(r_t.tobytes()).hexdigest())
+        print("    ", tag, hashes[tag])
+        org, d = ref.primary_rays(64, 64, CAM)
+        ids, t = ref.shoot(org, d); oi, ot = orc.shoot(org, d)
+        check(f"hit ids/t 64x64 {tag}", np.c_[ids, t], np.c_[oi, ot])
+        n = 20000
+        ro = rng.uniform(-1, 1, (n, 3)); rd = rng.uniform(-1, 1, (n, 3))
+        ids_r, t_r = ref.shoot(ro, rd); oi_r, ot_r = orc.shoot(ro, rd)
+        check(f"random-ray ids/t {tag}", np.c_[ids_r, t_r], np.c_[oi_r, ot_r])
+        # flat normals and colours at the hit points, then a shaded frame
+        hit = ids >= 0
+        pos = org[hit] + d[hit] * t[hit][:, None]
+        rn = ref.obj_normal(ids[hit], pos); on = orc.obj_normal(ids[hit], pos)
+        check(f"flat normals {tag}", rn, on)
+        ref.seed(12345); orc.seed(12345)
+        ref.emit_photons(3000); orc.emit_photons(3000)
+        ref.build_kdtree(); orc.build_kdtree()
+        rgb = ref.render(64, 64, CAM, intended=True)
+        orgb, _ = orc.render(64, 64, CAM, threads=4)
+        check(f"render 64x64 {tag}", rgb, orgb)
+        np.savez_compressed(os.path.join(GOLD, f"mesh_{tag}.npz"), rec=r_rec, boxes=r_box, dir64=d, ids64=ids, t64=t, org=ro, dir=rd, ids=ids_r, t=t_r,
+                            normals64=rn, rgb64=rgb, photons=ref.photons_get()[:, :9])
+    with open(os.path.join(GOLD, "idmap_hashes_no_normals.txt"), "w") as f:
+        for k, v in hashes.items():
+            f.write(f"{k} {v['hash']} {v['hits']} {v['mesh_hits']} {v['t_sha256']}\n")
+
+
+def finish():
     print()
     if failures:
         print("FAILED:", failures)
@@ -332,4 +471,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    # `python oracle/make_golden.py` writes everything; naming sections (base, intended, no_normals) writes only those
+    want = sys.argv[1:] or ["base", "intended", "no_normals"]
+    os.makedirs(DATA, exist_ok=True)
+    if "base" in want:
+        main()
+    if "intended" in want:
+        intended_mode()
+    if "no_normals" in want:
+        meshes_without_normals()
+    finish()

@@ -353,6 +353,235 @@ void ref_get_color_at(int64_t n, const double* pos, const double* dir, const int
     }
 }
 
+}  // extern "C"
+
+namespace {
+
+// The shade loop with the recursion the reference evidently means: a reflection / refraction ray that
+// hits something is continued on the object it HIT.  HEAD passes the object the ray LEFT (`hit_obj`,
+// main.cpp:198,249) and tests `hit_obj != nullptr` instead of the new hit (main.cpp:193,245), which
+// shades every mirror and glass surface black.  Everything here is the reference's own code --
+// bvh->Shoot, Object::getColor / getNormalAt / getRefraIdx, computeReflectionDir, computeGlossyRay,
+// Color and Vect arithmetic, and getColorAt itself for surfaces that spawn no ray (special <= 0: that
+// branch of main.cpp:260-390 does not recurse, so HEAD's code already is the intended code) -- driven
+// in the order of main.cpp:169-258 with those two tokens changed.
+Color shade_intended(Vect pos_in, Vect hit_dir, Object* hit_obj, double accuracy, double ambientLight, int depth)
+{
+    Color final_color(0, 0, 0, 0);
+    if (depth > TRACING_DEPTH) return final_color.clip();                       // main.cpp:161
+    Vect hit_pos = pos_in.vectAdd(hit_dir.vectMult(accuracy));                  // main.cpp:162
+    Color hit_color = hit_obj->getColor(hit_pos);                               // main.cpp:164
+    double colorSpecial = hit_color.getColorSpecial();
+    if (!(colorSpecial > 0)) return getColorAt(pos_in, hit_dir, hit_obj, accuracy, ambientLight, depth);
+    Vect hit_normal = hit_obj->getNormalAt(hit_pos);                            // main.cpp:165
+
+    Vect reflection_direction = computeReflectionDir(hit_normal, hit_dir);      // main.cpp:170
+    const double frac = colorSpecial * 100.0 - floor(colorSpecial * 100.0);
+    const double sample = (frac - 0.7654 < 0.0001 && frac - 0.7653 > 0) ? GLOSSY_SAMPLE : 1;   // main.cpp:177-179
+    Color reflect_sum(0, 0, 0, 0);
+    for (int i = 0; i < sample; i++) {                                          // main.cpp:181-206
+        Vect world_dir = sample != 1 ? computeGlossyRay(reflection_direction, hit_normal, 0.2) : reflection_direction;
+        Ray ray(hit_pos, world_dir);
+        double intersect_distance = 1e9;
+        Object* intersect_obj = bvh->Shoot(ray, intersect_distance);
+        if (intersect_obj != nullptr && intersect_distance > accuracy) {        // main.cpp:193, on the new hit
+            Vect next_pos = hit_pos.vectAdd(reflection_direction.vectMult(intersect_distance));
+            Color c = shade_intended(next_pos, reflection_direction, intersect_obj, accuracy, ambientLight, depth + 1);   // main.cpp:198
+            if (colorSpecial > 1) reflect_sum = reflect_sum.colorAdd(c.colorScalar(2 - hit_color.getColorSpecial()));
+            else reflect_sum = reflect_sum.colorAdd(c);
+        }
+    }
+    reflect_sum = reflect_sum.colorScalar(1.0 / sample);                        // main.cpp:207-208
+    final_color = final_color.colorAdd(reflect_sum);
+
+    if (colorSpecial > 1) {                                                     // main.cpp:210-258
+        Color refract_sum(0, 0, 0, 0);
+        for (int i = 0; i < sample; i++) {
+            double refractance = hit_color.getColorSpecial() - 1;
+            double n1n2 = 1.0 / hit_obj->getRefraIdx();
+            double dot1 = hit_normal.dotProduct(hit_dir.negtive());
+            if (dot1 < 0) {                                                     // (the flip persists into the later passes)
+                hit_normal = hit_normal.negtive();
+                dot1 = hit_normal.dotProduct(hit_dir.negtive());
+                n1n2 = 1.0 / n1n2;
+            }
+            double nNL = n1n2 * dot1;
+            double underSQRT = 1 - n1n2 * n1n2 * (1 - dot1 * dot1);
+            if (underSQRT > 0) {
+                double coeffN = nNL - sqrt(underSQRT);
+                Vect refraction_direction = hit_normal.vectMult(coeffN).vectAdd((hit_dir.negtive().vectMult(n1n2)).negtive());
+                Vect world_dir = sample != 1 ? computeGlossyRay(refraction_direction, hit_normal, 0.2) : refraction_direction;
+                Ray ray(hit_pos, world_dir);
+                double intersect_distance = 1e9;
+                Object* intersect_obj = bvh->Shoot(ray, intersect_distance);
+                if (intersect_obj != nullptr && intersect_distance > accuracy) {    // main.cpp:245, on the new hit
+                    Vect next_pos = hit_pos.vectAdd(refraction_direction.vectMult(accuracy + intersect_distance));
+                    Color c = shade_intended(next_pos, refraction_direction, intersect_obj, accuracy, ambientLight, depth + 1);   // main.cpp:249
+                    refract_sum = refract_sum.colorAdd(c.colorScalar(refractance));
+                }
+            }
+            refract_sum = refract_sum.colorScalar(1.0 / sample);                // main.cpp:255-256, inside the loop as there
+            final_color = final_color.colorAdd(refract_sum);
+        }
+    }
+    return final_color.clip();                                                  // main.cpp:391
+}
+
+// Camera basis of main.cpp:626-635 and the sample position of main.cpp:753-787 (aax serves both offsets
+// when aadepth > 1), with the reference's own Vect operations.
+struct RefCam { Vect pos, dir, right, down; };
+RefCam ref_cam(const double* cam)
+{
+    Vect Y(0, 1, 0);
+    Vect camPos(cam[0], cam[1], cam[2]);
+    Vect look_at(cam[3], cam[4], cam[5]);
+    Vect diff_btw(camPos.getVectX() - look_at.getVectX(), camPos.getVectY() - look_at.getVectY(), camPos.getVectZ() - look_at.getVectZ());
+    RefCam c;
+    c.pos = camPos;
+    c.dir = diff_btw.negtive().normalize();
+    c.right = Y.crossProduct(c.dir).normalize();
+    c.down = c.right.crossProduct(c.dir);
+    return c;
+}
+Vect ref_cam_dir(const RefCam& c, int width, int height, int aadepth, int x, int y, int aax)
+{
+    double aspectRatio = (double)width / (double)height;
+    double xamnt, yamnt;
+    if (aadepth == 1) {
+        if (width > height) {
+            xamnt = ((x + 0.5) / width) * aspectRatio - (((width - height) / (double)height) / 2);
+            yamnt = ((height - y) + 0.5) / height;
+        } else if (height > width) {
+            xamnt = (x + 0.5) / width;
+            yamnt = (((height - y) + 0.5) / height) / aspectRatio - (((height - width) / (double)width) / 2);
+        } else {
+            xamnt = (x + 0.5) / width;
+            yamnt = ((height - y) + 0.5) / height;
+        }
+    } else {
+        if (width > height) {
+            xamnt = ((x + (double)aax / ((double)aadepth - 1)) / width) * aspectRatio - (((width - height) / (double)height) / 2);
+            yamnt = ((height - y) + (double)aax / ((double)aadepth - 1)) / height;
+        } else if (height > width) {
+            xamnt = (x + (double)aax / ((double)aadepth - 1)) / width;
+            yamnt = (((height - y) + (double)aax / ((double)aadepth - 1)) / height) / aspectRatio - (((height - width) / (double)width) / 2);
+        } else {
+            xamnt = (x + (double)aax / ((double)aadepth - 1)) / width;
+            yamnt = ((height - y) + (double)aax / ((double)aadepth - 1)) / height;
+        }
+    }
+    return c.dir.vectAdd(c.right.vectMult(xamnt - 0.5).vectAdd(c.down.vectMult(yamnt - 0.5))).normalize();
+}
+
+}  // namespace
+
+extern "C" {
+
+// shade_intended for a batch of hits (same arguments as ref_get_color_at)
+void ref_color_intended(int64_t n, const double* pos, const double* dir, const int32_t* obj, int depth, double* rgb)
+{
+    for (int64_t i = 0; i < n; i++) {
+        Color c = shade_intended(Vect(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), Vect(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]),
+                                 scene_objects.at(obj[i]), 0.000001, 0, depth);
+        rgb[3 * i] = c.getColorRed(); rgb[3 * i + 1] = c.getColorGreen(); rgb[3 * i + 2] = c.getColorBlue();
+    }
+}
+
+// One ray per (pixel, aax): the aadepth distinct camera rays of a pixel (main.cpp:771-787); dir = w*h*aadepth*3
+void ref_primary_rays_aa(int w, int h, int aadepth, const double* cam, double* org, double* dir)
+{
+    RefCam c = ref_cam(cam);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int a = 0; a < aadepth; a++) {
+                size_t i = ((size_t)y * w + x) * aadepth + a;
+                Vect d = ref_cam_dir(c, w, h, aadepth, x, y, a);
+                org[3 * i] = c.pos.getVectX(); org[3 * i + 1] = c.pos.getVectY(); org[3 * i + 2] = c.pos.getVectZ();
+                dir[3 * i] = d.getVectX(); dir[3 * i + 1] = d.getVectY(); dir[3 * i + 2] = d.getVectZ();
+            }
+}
+
+// The pixel loop of main.cpp:737-859 (DOF_SAMPLE 1), one thread, rows outermost (the reference's threads walk
+// column strips; pixels only interact through the shared generator).  intended = 0 shades with the
+// reference's getColorAt, 1 with shade_intended.  rgb: h x w x 3, pixel index y*w+x as main.cpp:739.
+void ref_render(int w, int h, int aadepth, const double* cam, int intended, double* rgb)
+{
+    RefCam c = ref_cam(cam);
+    const double accuracy = 0.000001, ambientLight = 0;
+    std::vector<double> tempRed(aadepth * aadepth), tempGreen(aadepth * aadepth), tempBlue(aadepth * aadepth);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            for (int aax = 0; aax < aadepth; aax++)
+                for (int aay = 0; aay < aadepth; aay++) {
+                    int aa_index = aay * aadepth + aax;
+                    Vect cam_ray_direction = ref_cam_dir(c, w, h, aadepth, x, y, aax);
+                    Ray cam_ray(c.pos, cam_ray_direction);
+                    double dofColor[3] = {0, 0, 0};
+                    double intersect_distance = 1e9;
+                    Object* intersect_obj = bvh->Shoot(cam_ray, intersect_distance);                  // main.cpp:812-813
+                    if (intersect_obj != nullptr && intersect_distance > accuracy) {                  // main.cpp:815-820
+                        Vect ipos = cam_ray.getRayOrigin().vectAdd(cam_ray_direction.vectMult(intersect_distance));
+                        Color col = intended ? shade_intended(ipos, cam_ray_direction, intersect_obj, accuracy, ambientLight, 1)
+                                             : getColorAt(ipos, cam_ray_direction, intersect_obj, accuracy, ambientLight, 1);
+                        dofColor[0] += col.getColorRed(); dofColor[1] += col.getColorGreen(); dofColor[2] += col.getColorBlue();
+                    }
+                    tempRed[aa_index] = dofColor[0] / DOF_SAMPLE;                                     // main.cpp:831-833
+                    tempGreen[aa_index] = dofColor[1] / DOF_SAMPLE;
+                    tempBlue[aa_index] = dofColor[2] / DOF_SAMPLE;
+                }
+            double totalRed = 0, totalGreen = 0, totalBlue = 0;                                       // main.cpp:839-859
+            for (int i = 0; i < aadepth * aadepth; i++) totalRed += tempRed[i];
+            for (int i = 0; i < aadepth * aadepth; i++) totalGreen += tempGreen[i];
+            for (int i = 0; i < aadepth * aadepth; i++) totalBlue += tempBlue[i];
+            size_t px = (size_t)y * w + x;
+            rgb[3 * px] = totalRed / (aadepth * aadepth);
+            rgb[3 * px + 1] = totalGreen / (aadepth * aadepth);
+            rgb[3 * px + 2] = totalBlue / (aadepth * aadepth);
+        }
+}
+
+// A mesh whose faces carry no normal index (`f v/vt`, teapot1.obj, or `f v`, test.obj): the reference's own reader
+// dereferences a null strtok result on them (IO.h:93), so the harness reads the file the way IO.h:75-119
+// does -- words from the stream, offsets added as floats (IO.h:82), Triangle(points[v1], points[v2],
+// points[v3]) (IO.h:103), setTexture where the face has texture indices (IO.h:105) -- and leaves out only the
+// setNormals call the file has no data for: every such triangle shades with its flat normal.
+int ref_scene_load_obj_no_normals(const char* path, double r, double g, double b, double special, float ior,
+                                  float xo, float yo, float zo, int use_texture, int map_idx)
+{
+    std::fstream input(path, std::ios::in);
+    if (!input) return 0;
+    std::vector<Vect> points;
+    std::vector<MyTexture> textures;
+    std::string head;
+    while (input >> head) {
+        if (head == "v") {
+            double a, b2, c2;
+            input >> a >> b2 >> c2;
+            points.push_back(Vect(a + xo, b2 + yo, c2 + zo));
+        } else if (head == "vt") {
+            double a, b2;
+            input >> a >> b2;
+            textures.push_back(MyTexture(a, b2));
+        } else if (head == "f") {
+            std::string corner[3];
+            input >> corner[0] >> corner[1] >> corner[2];
+            if (!input) break;
+            int v[3], vt[3];
+            for (int k = 0; k < 3; k++) {
+                v[k] = atoi(corner[k].c_str()) - 1;
+                size_t slash = corner[k].find('/');
+                vt[k] = (slash != std::string::npos && slash + 1 < corner[k].size() && corner[k][slash + 1] != '/') ? atoi(corner[k].c_str() + slash + 1) - 1 : -1;
+            }
+            Triangle* t = new Triangle(points.at(v[0]), points.at(v[1]), points.at(v[2]), Color(r, g, b, special), ior);
+            if (vt[0] >= 0 && vt[1] >= 0 && vt[2] >= 0)
+                t->setTexture(textures.at(vt[0]), textures.at(vt[1]), textures.at(vt[2]), use_texture != 0 && map_idx >= 0,
+                              map_idx >= 0 ? g_maps.at(map_idx) : new TextureMap());
+            scene_objects.push_back(t);
+        }
+    }
+    return 1;
+}
+
 // computeReflectionDir (main.cpp:125)
 void ref_reflect_dir(int64_t n, const double* nrm, const double* dir, double* out)
 {

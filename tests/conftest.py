@@ -31,9 +31,9 @@ def build_scene(api, mesh="teapot_normal.obj", rgbs=(0.5, 0.5, 0.5, 0.0), ior=1.
     return api
 
 
-def golden_hashes():
+def golden_hashes(name="idmap_hashes.txt"):
     out = {}
-    with open(os.path.join(GOLD, "idmap_hashes.txt")) as f:
+    with open(os.path.join(GOLD, name)) as f:
         for line in f:
             tag, h, hits, mesh_hits, tsha = line.split()
             out[tag] = dict(hash=h, hits=int(hits), mesh_hits=int(mesh_hits), t_sha256=tsha)

@@ -137,4 +137,41 @@ def test_ten_million_triangles_two_trees_one_image(gpu_ctx):
     assert np.array_equal(np.where(ids_l >= 0, t_l, 1e9), np.where(ids_r >= 0, t_r, 1e9))
     assert (ids_l != ids_r).mean() < 1e-4
     assert ms > 0 and ids_r.max() < s.size()
+
+    # The same configuration through the full pixel path at 16 samples per pixel (aadepth 4: main.cpp:771-787 shoots
+    # 16 camera rays per pixel of which 4 are distinct), 7680x4320, with a photon map so that the frame is not black:
+    # 132.7 M traced camera rays per frame.  The frame of the device-built tree equals the frame of the reference's
+    # tree (same photon map), and a pixel's 16-sample value lies within the range its neighbourhood spans at 1 sample.
+    import ctypes
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")                    # the runtime the library itself uses
+
+    def render_bgr8(params):
+        d = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(d), ctypes.c_size_t(h * w * 3)) == 0
+        st_ = gpu_ctx.render_dev(cam, params, (0, h), None, d)
+        out = np.zeros((h, w, 3), np.uint8)
+        assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), d, ctypes.c_size_t(h * w * 3), 2) == 0
+        assert hip.hipFree(d) == 0
+        return out, st_
+    light = (side * 0.5, c, c)
+    (n_surface, _), _ = gpu_ctx.emit_photon_maps(2_000_000, light_pos=light, seed=7)
+    assert n_surface > 100_000
+    frames = []
+    for tree in ("device", "reference"):
+        if tree == "reference":
+            gpu_ctx.upload(s)
+        p16 = rt.default_params(width=w, height=h, aadepth=4, photon_num=2_000_000, photon_use=50)
+        frame, st16 = render_bgr8(p16)
+        assert st16.primary_rays == w * h * 4 and st16.secondary_rays == 0
+        assert st16.gather_queries > 4 * 9000000
+        frames.append(frame)
+    differ = (frames[0] != frames[1]).any(-1).mean()
+    assert differ < 1e-3, differ
+    assert frames[1].max() > 50 and (frames[1].sum(-1) > 0).mean() > 0.05     # a lit frame
+    one = render_bgr8(rt.default_params(width=w, height=h, aadepth=1, photon_num=2_000_000, photon_use=50))[0].astype(np.int32)
+    sixteen = frames[1].astype(np.int32)
+    # camera rays of aadepth 4 leave pixel (x, y) between the centres of pixels (x - 1 .. x + 1, y - 1 .. y + 1)
+    interior = (one[1:-1, 1:-1].sum(-1) > 0) & (one[:-2, 1:-1].sum(-1) > 0) & (one[2:, 1:-1].sum(-1) > 0) & (one[1:-1, :-2].sum(-1) > 0) & (one[1:-1, 2:].sum(-1) > 0)
+    assert np.abs(sixteen[1:-1, 1:-1][interior].mean() - one[1:-1, 1:-1][interior].mean()) < 2.0
+    gpu_ctx.photons_upload(np.zeros((0, 9)))
     gpu_ctx.upload(build_scene(rt.Scene()))                                  # leave a small scene behind

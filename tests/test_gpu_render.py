@@ -105,6 +105,44 @@ def test_render_golden_head_semantics(gpu_ctx, tag):
     assert st.primary_rays == 64 * 64
 
 
+@pytest.mark.parametrize("tag,mesh", [("mirror", "teapot_normal.obj"), ("glass", "teapot_normal.obj"), ("water", "water.obj")])
+def test_render_golden_intended_recursion(gpu_ctx, tag, mesh):
+    """The default mode (head_quirk = 0: a bounce is continued on the object it hit) against 64x64 frames that the
+    reference's own Shoot / getColor / getNormalAt / computeReflectionDir / getColorAt produced when driven with that
+    recursion (HEAD's getColorAt passes the old object on, main.cpp:198,249, and shades mirrors and glass black)."""
+    g = golden(f"render_{tag}_intended_64.npz")
+    s = build_scene(rt.Scene(), mesh, tuple(g["rgbs"]), float(g["ior"]), tuple(g["off"]))
+    s.emit_photons(3000, seed=12345)
+    assert np.array_equal(sort_rows(s.photons_get()), sort_rows(g["photons"]))
+    gpu_ctx.upload(s)
+    gpu_ctx.photons_upload(s.photons_get())
+    p = rt.default_params(width=64, height=64)
+    assert p.head_quirk == 0
+    rgb, bgr, st = gpu_ctx.render(rt.look_at(CAM[:3], CAM[3:]), p)
+    within, rmse = assert_image_close(rgb, g["rgb"], what=tag + " (recursion on the new hit)")
+    assert np.abs(rgb - g["rgb"]).max() < 2e-3
+    assert st.secondary_rays > 0
+    mesh_px = gpu_ctx.trace_primary(rt.look_at(CAM[:3], CAM[3:]), rt.default_params(width=64, height=64))[0] < s.size() - 10
+    assert g["rgb"].reshape(-1, 3)[mesh_px].max() > 0.02                      # the reflecting / refracting mesh is not black
+
+
+def test_render_golden_textures_spheres_aa(gpu_ctx):
+    """Textured smooth-normal triangles + the reference's mirror and glass spheres at aadepth 1, 2 and 4 (main.cpp:771-787:
+    aadepth^2 samples of which aadepth are distinct) against frames the reference's own functions produced."""
+    from test_oracle_golden import tex_spheres_scene
+    g = golden("render_texspheres_intended.npz")
+    s = rt.Scene()
+    tex_spheres_scene(s, s.add_texture_bmp(DATA + "/tex.bmp"))
+    s.emit_photons(3000, seed=3)
+    assert np.array_equal(sort_rows(s.photons_get()), sort_rows(g["photons"]))
+    gpu_ctx.upload(s); gpu_ctx.photons_upload(s.photons_get())
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    for (w, h, aa) in [(96, 72, 1), (80, 60, 2), (80, 60, 4)]:
+        rgb, bgr, st = gpu_ctx.render(cam, rt.default_params(width=w, height=h, aadepth=aa))
+        assert_image_close(rgb, g[f"rgb_{w}x{h}_aa{aa}"], what=f"textured + spheres {w}x{h} aadepth {aa}")
+        assert st.primary_rays == w * h * aa
+
+
 @pytest.mark.parametrize("tag,rgbs,ior", [("mirror", (1.0, 1.0, 1.0, 0.9), 1.5), ("glass", (1.0, 1.0, 1.0, 1.8), 1.5),
                                           ("water", (0.26, 0.84, 1.0, 1.8), 1.33)])
 def test_render_intended_recursion(gpu_ctx, tag, rgbs, ior):
@@ -155,7 +193,7 @@ def test_render_textures_spheres_and_aa(gpu_ctx):
     orc.photons_set(np.c_[ph, np.zeros(len(ph))]); orc.build_kdtree()
     gpu_ctx.upload(s); gpu_ctx.photons_upload(ph)
     cam = rt.look_at(CAM[:3], CAM[3:])
-    for aa in (1, 2, 3):
+    for aa in (1, 2, 3, 4):
         w, h = 80, 60
         p = rt.default_params(width=w, height=h, aadepth=aa)
         rgb, bgr, st = gpu_ctx.render(cam, p)

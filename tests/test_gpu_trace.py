@@ -301,3 +301,31 @@ def test_f32_instantiation_bit_exact(gpu_ctx, scenes):
     org, d = orc.primary_rays(320, 200, cam_v)
     oid, ot = orc.shoot_f32(org, d)
     assert eq(ids, oid) and eq(np.where(ids >= 0, t, 1e9), ot)
+
+
+@pytest.mark.parametrize("tag", ["teapot1", "test"])
+def test_meshes_without_normals(gpu_ctx, tag):
+    """teapot1.obj (`f v/vt` faces: the mesh the second BASELINE configuration names) and test.obj through
+    rt_scene_load_obj: tree, ids and t bit for bit against what the compiled reference traced on the same triangles
+    (built by the harness's reader, since the reference's own crashes on faces without a normal index, IO.h:93)."""
+    g = golden(f"mesh_{tag}.npz")
+    s = build_scene(rt.Scene(), tag + ".obj")
+    rec, boxes = s.bvh_dump()
+    assert eq(rec, g["rec"]) and eq(boxes, g["boxes"])
+    gpu_ctx.upload(s)
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    ids, t, _, _ = gpu_ctx.trace_primary(cam, rt.default_params(width=64, height=64))
+    assert eq(ids, g["ids64"]) and eq(np.where(ids >= 0, t, 1e9), g["t64"])
+    ids, t = gpu_ctx.trace_closest(g["org"], g["dir"])
+    assert eq(ids, g["ids"]) and eq(t, g["t"])
+    ids, t, _, st = gpu_ctx.trace_primary(cam, rt.default_params(width=1920, height=1080))
+    h = golden_hashes("idmap_hashes_no_normals.txt")[tag]
+    assert id_map_hash(ids) == h["hash"] and int((ids >= 0).sum()) == h["hits"]
+    assert int(((ids >= 0) & (ids < s.size() - 10)).sum()) == h["mesh_hits"]
+    assert hashlib.sha256(np.where(ids >= 0, t, 1e9).tobytes()).hexdigest() == h["t_sha256"]
+    # flat-normal shading of the same mesh: the frame the reference's getColorAt produced
+    s.emit_photons(3000, seed=12345)
+    gpu_ctx.photons_upload(s.photons_get())
+    rgb, _, _ = gpu_ctx.render(cam, rt.default_params(width=64, height=64))
+    a = np.floor(np.clip(rgb, 0, 1) * 255).astype(np.int32); b = np.floor(np.clip(g["rgb64"], 0, 1) * 255).astype(np.int32)
+    assert (np.abs(a - b).max(-1) <= 1).mean() >= 0.999 and np.abs(rgb - g["rgb64"]).max() < 2e-3

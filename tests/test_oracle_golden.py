@@ -291,3 +291,112 @@ def test_single_precision_restatement_tracks_the_double_one():
     d[::7] = np.nan
     i32, t32 = orc.shoot_f32(org, d)
     assert (i32[::7] == -1).all() and (t32[::7] == 1e9).all()
+
+
+# ---- the recursion on the newly hit object (the product's default mode), pinned by frames the reference's
+# own Shoot / getColor / getNormalAt / computeReflectionDir / computeGlossyRay / getColorAt produced under
+# oracle/ref_harness.cpp's shade loop (HEAD's getColorAt recurses on the old object, main.cpp:198,249)
+
+@pytest.mark.parametrize("tag,mesh", [("mirror", "teapot_normal.obj"), ("glass", "teapot_normal.obj"), ("water", "water.obj")])
+def test_render_intended_recursion_golden(tag, mesh):
+    g = golden(f"render_{tag}_intended_64.npz")
+    orc = build_scene(Oracle(), mesh, tuple(g["rgbs"]), float(g["ior"]), tuple(g["off"]))
+    orc.seed(12345)
+    orc.emit_photons(3000)
+    orc.build_kdtree()
+    assert eq(orc.photons_get()[:, :9], g["photons"])
+    orc.params.head_quirk = 0
+    rgb, _ = orc.render(64, 64, CAM, threads=4)
+    assert eq(rgb, g["rgb"])
+    orc.params.head_quirk = 1
+    head, _ = orc.render(64, 64, CAM, threads=4)
+    assert (np.abs(head - g["rgb"]).max(-1) > 1e-3).sum() > 100      # the two modes are different frames
+
+
+def tex_spheres_scene(api, tex):
+    r2 = np.random.default_rng(5)
+    for i in range(30):
+        c = r2.uniform(-0.7, 0.7, 3)
+        A, C, B = c + r2.uniform(-0.35, 0.35, (3, 3))
+        o = api.add_triangle(A, C, B, (0.8, 0.7, 0.6, 0.0), 1.3)
+        nn = r2.normal(size=(3, 3)); nn /= np.linalg.norm(nn, axis=1)[:, None]
+        tt = r2.uniform(-1, 2, (3, 2))
+        if hasattr(api, "last_set_normals"):
+            api.last_set_normals(nn[0], nn[1], nn[2]); api.last_set_texture(tt[0], tt[1], tt[2], True, tex)
+        else:
+            api.set_normals(o, nn[0], nn[1], nn[2]); api.set_texture(o, tt[0], tt[1], tt[2], True, tex)
+    api.add_sphere((0.3, -0.4, -0.4), 0.3, (1.0, 1.0, 1.0, 0.9), 1.5)     # the reference's two spheres (main.cpp:623-668)
+    api.add_sphere((0.3, -0.7, 0.4), 0.3, (1.0, 1.0, 1.0, 1.8), 1.5)
+    api.add_cornell()
+    api.build_bvh()
+    return api
+
+
+def test_render_textures_spheres_aa_golden():
+    """Textured smooth-normal triangles, mirror and glass spheres, the anti-aliasing sample pattern of
+    main.cpp:771-787 at aadepth 1, 2 and 4 (16 samples per pixel, 4 of them distinct)."""
+    g = golden("render_texspheres_intended.npz")
+    orc = Oracle()
+    tex_spheres_scene(orc, orc.texture_read(DATA + "/tex.bmp"))
+    orc.seed(3)
+    orc.emit_photons(3000)
+    orc.build_kdtree()
+    assert eq(orc.photons_get()[:, :9], g["photons"])
+    orc.params.head_quirk = 0
+    for (w, h, aa) in [(96, 72, 1), (80, 60, 2), (80, 60, 4)]:
+        rgb, _ = orc.render(w, h, CAM, aadepth=aa, threads=8)
+        assert eq(rgb, g[f"rgb_{w}x{h}_aa{aa}"]), (w, h, aa)
+
+
+def test_glossy_intended_recursion_golden():
+    """The 16 + 16 jittered rays of a glossy hit with the recursion on the new hit, drawing from the shared mt19937
+    in the reference's order."""
+    g = golden("glossy_intended.npz")
+    orc = _glossy_scene_diffuse_teapot(Oracle())
+    orc.seed(4242)
+    orc.emit_photons(400)
+    assert eq(orc.photons_get(0)[:, :9], g["photons"])
+    orc.build_kdtree()
+    orc.params.head_quirk = 0
+    orc.seed(99)
+    rgb = orc.get_color_at(g["pos"], g["dir"], g["ids"], 1)
+    assert eq(rgb, g["rgb"]) and g["rgb"].max() > 0
+
+
+def _glossy_scene_diffuse_teapot(api):
+    api.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0, -0.7, 0))
+    api.add_sphere((0.0, 0.35, 0.55), 0.3, (1.0, 1.0, 1.0, 0.987654), 1.0)
+    api.add_sphere((0.0, 0.35, -0.55), 0.3, (1.0, 1.0, 1.0, 1.887654), 1.5)
+    api.add_cornell()
+    api.build_bvh()
+    return api
+
+
+# ---- meshes whose faces carry no normal index (teapot1.obj is the mesh BASELINE's second configuration names)
+
+@pytest.mark.parametrize("tag", ["teapot1", "test"])
+def test_mesh_without_normals_golden(tag):
+    g = golden(f"mesh_{tag}.npz")
+    orc = build_scene(Oracle(), tag + ".obj")
+    rec, boxes = orc.bvh_dump()
+    assert eq(rec, g["rec"]) and eq(boxes, g["boxes"])
+    org, d = orc.primary_rays(64, 64, CAM)
+    assert eq(d, g["dir64"])
+    ids, t = orc.shoot(org, d)
+    assert eq(ids, g["ids64"]) and eq(t, g["t64"])
+    ids, t = orc.shoot(g["org"], g["dir"])
+    assert eq(ids, g["ids"]) and eq(t, g["t"])
+    hit = g["ids64"] >= 0
+    pos = org[hit] + d[hit] * g["t64"][hit][:, None]
+    assert eq(orc.obj_normal(g["ids64"][hit], pos), g["normals64"])
+    orc.seed(12345)
+    orc.emit_photons(3000)
+    orc.build_kdtree()
+    assert eq(orc.photons_get()[:, :9], g["photons"])
+    rgb, _ = orc.render(64, 64, CAM, threads=4)
+    assert eq(rgb, g["rgb64"])
+    org, d = orc.primary_rays(1920, 1080, CAM)
+    ids, t = orc.shoot_mt(org, d, threads=8)
+    h = golden_hashes("idmap_hashes_no_normals.txt")[tag]
+    assert id_map_hash(ids) == h["hash"] and int((ids >= 0).sum()) == h["hits"]
+    assert hashlib.sha256(t.tobytes()).hexdigest() == h["t_sha256"]
