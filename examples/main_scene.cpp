@@ -26,6 +26,7 @@
 
 BVH* bvh;
 KDTree* kdtree;
+KDTree* volumeKDTree;
 vector<Photon*> photons;
 vector<Photon*> volumePhotons;
 vector<Object*> scene_objects;
@@ -33,7 +34,7 @@ vector<Object*> scene_objects;
 int main(int argc, char* argv[])
 {
     if (argc < 3) {
-        fprintf(stderr, "usage: %s mesh.obj out.bmp [width height photons seed special ior yoff]\n", argv[0]);
+        fprintf(stderr, "usage: %s mesh.obj out.bmp [width height photons seed special ior yoff red green blue PHOTONMUM]\n", argv[0]);
         return 2;
     }
     int dpi = 72;
@@ -44,6 +45,8 @@ int main(int argc, char* argv[])
     double special = argc > 7 ? atof(argv[7]) : 1.8;
     float ior = argc > 8 ? (float)atof(argv[8]) : 1.5f;
     float yoff = argc > 9 ? (float)atof(argv[9]) : -0.7f;
+    double red = argc > 10 ? atof(argv[10]) : 1.0, green = argc > 11 ? atof(argv[11]) : 1.0, blue = argc > 12 ? atof(argv[12]) : 1.0;
+    long long photonmum = argc > 13 ? atoll(argv[13]) : photon_count;      // PHOTONMUM of the radiance estimate (main.cpp:21,293)
 
     RGBType* pixels = new RGBType[(size_t)width * height];
 
@@ -57,7 +60,7 @@ int main(int argc, char* argv[])
     Camera scene_cam(camPos, camDir, camRight, camDown);
 
     Color white_light(1.0, 1.0, 1.0, 0.0);
-    Color mesh_color(1.0, 1.0, 1.0, special);
+    Color mesh_color(red, green, blue, special);
     Vect light_position(0.1, 0.2, 0);
     Light scene_light(light_position, white_light);
 
@@ -71,18 +74,29 @@ int main(int argc, char* argv[])
 
     Renderer renderer(bvh);
     renderer.emitPhotons(photon_count, scene_light.getLightPosition(), seed, photons, volumePhotons);
-    kdtree = new KDTree(photons, 0, device_tree && atoi(device_tree) != 0);
+    // main.cpp:724-728, constructor calls as written there: the first tree is the surface map, the second the volume map
+    if (device_tree && atoi(device_tree) != 0) {
+        kdtree = new KDTree(photons, 0, true);
+        if (volumePhotons.size() > 3) volumeKDTree = new KDTree(volumePhotons, 1, true);
+    } else {
+        kdtree = new KDTree(photons);
+        if (volumePhotons.size() > 3) volumeKDTree = new KDTree(volumePhotons);
+    }
 
     // one probe through the single-ray API, as main.cpp's loops would issue it
     double d = 1e9;
     Object* first = bvh->Shoot(Ray(camPos, camDir), d);
-    printf("objects %zu, photons %zu, centre ray hits %s at %.17g\n", scene_objects.size(), photons.size(), first ? "an object" : "nothing", d);
+    printf("objects %zu, photons %zu + %zu, centre ray hits %s at %.17g\n", scene_objects.size(), photons.size(), volumePhotons.size(), first ? "an object" : "nothing", d);
 
     RenderParams params;
     params.width = width;
     params.height = height;
-    params.photon_num = (int)photon_count;
-    rt_stats st = renderer.render(scene_cam, params, pixels);
+    params.photon_num = (int)photonmum;
+    rt_stats st;
+    if (renderer.render(scene_cam, params, pixels, &st) < 0) {
+        fprintf(stderr, "render failed: %s\n", renderer.last_error().c_str());
+        return 1;
+    }
     printf("rays: %llu primary, %llu secondary, %llu gathers; device %.3f ms\n", (unsigned long long)st.primary_rays,
            (unsigned long long)st.secondary_rays, (unsigned long long)st.gather_queries, st.kernel_ms);
 

@@ -36,7 +36,8 @@ typedef enum rt_status {
     RT_ERR_HIP = -3,          /* a HIP call or kernel launch failed                              */
     RT_ERR_STATE = -4,        /* call order violated (e.g. trace before scene upload)            */
     RT_ERR_IO = -5,           /* file could not be read / written                                */
-    RT_ERR_LIMIT = -6         /* a compiled-in limit was exceeded (e.g. BVH deeper than the traversal stack) */
+    RT_ERR_LIMIT = -6,        /* a compiled-in limit was exceeded (e.g. BVH deeper than the traversal stack) */
+    RT_ERR_NOMEM = -7         /* a host allocation failed                                         */
 } rt_status;
 
 /* arithmetic the kernels run in.  RT_F64 reproduces the reference bit for bit (hit ids, t);
@@ -109,7 +110,7 @@ void rt_context_destroy(rt_context* ctx);
 void* rt_context_stream(rt_context* ctx);
 /* Waits for the context's stream.  The *_dev entry points called without `stats` do not wait for their
  * kernels; if one of those kernels ran out of traversal stack or queue room (its output is then incomplete)
- * the device remembers it and this call returns RT_ERR_LIMIT, once.  Calls that do wait report it themselves. */
+ * the context remembers it and this call returns RT_ERR_LIMIT, once.  Calls that do wait report it themselves. */
 int rt_context_synchronize(rt_context* ctx);
 void rt_default_params(rt_render_params* p);
 /* camera basis from position + look-at, main.cpp:626-635 */

@@ -220,10 +220,16 @@ int Scene::add_texture_bmp(const char* path)
     t.x_res = header[22] | header[23] << 8 | header[24] << 16 | header[25] << 24;
     if (t.x_res <= 0 || t.y_res <= 0) { fclose(fp); return -1; }
     size_t n = (size_t)t.x_res * t.y_res;
+    // The header is not trusted: the texels it announces must be in the file (the reference would read past
+    // the end into an uninitialised buffer, TextureMap.h:45-53; a corrupt size must not become a huge allocation).
+    long data_at = ftell(fp);
+    if (data_at < 0 || fseek(fp, 0, SEEK_END) != 0) { fclose(fp); return -1; }
+    long file_end = ftell(fp);
+    if (file_end < data_at || (unsigned long long)(file_end - data_at) < (unsigned long long)n * 3ull || fseek(fp, data_at, SEEK_SET) != 0) { fclose(fp); return -1; }
     std::vector<unsigned char> raw(n * 3, 0);
     size_t got = fread(raw.data(), 1, raw.size(), fp);   // no row padding is skipped, as in the reference
-    (void)got;
     fclose(fp);
+    if (got != raw.size()) return -1;
     t.rgb.resize(n * 3);
     for (size_t i = 0; i < n; i++) {
         t.rgb[3 * i] = raw[3 * i + 2] / 255.0;       // file order is B, G, R (TextureMap.h:50-53)

@@ -6,6 +6,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -41,6 +43,21 @@ int fail(int code, const char* fmt, ...)
         hipError_t e_ = (expr);                                                                \
         if (e_ != hipSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
+
+// No exception crosses the C boundary: an entry point's body runs inside this.
+template <class F>
+int guarded(F&& body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(RT_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(RT_ERR_INVALID, "%s", e.what());
+    } catch (...) {
+        return fail(RT_ERR_INVALID, "unknown exception");
+    }
+}
 
 struct DevBuf {
     void* p = nullptr;
@@ -83,6 +100,7 @@ struct rt_context {
     int num_cus = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> chunk_ev;   // begin / end of the trace + shade launches of every row chunk of a timed frame
     // flattened scene in HBM, both instantiations
     DevBuf nodes64, prims64, planes64, nodes32, prims32, planes32, objs, texdesc, texels;
     rtf::SceneView<double> v64{};
@@ -122,22 +140,20 @@ const rtf::SceneView<R>& view(const rt_context* ctx);
 template <> const rtf::SceneView<double>& view<double>(const rt_context* ctx) { return ctx->v64; }
 template <> const rtf::SceneView<float>& view<float>(const rt_context* ctx) { return ctx->v32; }
 
-// The device's overflow latch (the stream must be idle): read into v and cleared when set.
-int take_overflow_latch(unsigned long long v[2])
+// The context's overflow latch (its stream must be idle): read into v and cleared when set.
+int take_overflow_latch(rt_context* ctx, unsigned long long v[2])
 {
-    HIP_TRY(hipMemcpyFromSymbol(v, HIP_SYMBOL(rtk::g_overflow_latch), 2 * sizeof(unsigned long long)));
-    if (v[0] | v[1]) {
-        const unsigned long long zero[2] = {0, 0};
-        HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(rtk::g_overflow_latch), zero, sizeof zero));
-    }
+    char* latch = (char*)ctx->counters.p + rtk::LATCH_OFFSET;
+    HIP_TRY(hipMemcpy(v, latch, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    if (v[0] | v[1]) HIP_TRY(hipMemset(latch, 0, 2 * sizeof(unsigned long long)));
     return RT_OK;
 }
 
 // An overflow found in a call's own counters: reported now, so the latch is cleared with it.
-int overflow_error(const char* what)
+int overflow_error(rt_context* ctx, const char* what)
 {
     unsigned long long v[2];
-    int rc = take_overflow_latch(v);
+    int rc = take_overflow_latch(ctx, v);
     return rc ? rc : fail(RT_ERR_LIMIT, "%s", what);
 }
 
@@ -262,13 +278,16 @@ const char* rt_last_error(void) { return g_err.c_str(); }
 
 int rt_device_count(void)
 {
+    return guarded([&]() -> int {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+    });
 }
 
 int rt_context_create(int device, rt_context** out)
 {
+    return guarded([&]() -> int {
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
     *out = nullptr;
     int n = 0;
@@ -288,10 +307,15 @@ int rt_context_create(int device, rt_context** out)
     }
     for (auto& ev : ctx->ev)
         if (hipEventCreate(&ev) != hipSuccess) { delete ctx; return fail(RT_ERR_HIP, "hipEventCreate failed"); }
-    int rc = ctx->counters.reserve(std::max<size_t>(1024, sizeof(rtr::RenderCounters)));
+    // per-call counter block of every kernel family + the overflow latch behind it; never reallocated
+    static_assert(sizeof(rtr::RenderCounters) <= rtk::LATCH_OFFSET && sizeof(rte::EmitCounters) <= rtk::LATCH_OFFSET && sizeof(rtk::TraceCounters) <= rtk::LATCH_OFFSET,
+                  "the counter blocks end before the overflow latch");
+    int rc = ctx->counters.reserve(rtk::LATCH_OFFSET + 64);
     if (rc) { delete ctx; return rc; }
+    if (hipMemset(ctx->counters.p, 0, rtk::LATCH_OFFSET + 64) != hipSuccess) { rt_context_destroy(ctx); return fail(RT_ERR_HIP, "hipMemset failed"); }
     *out = ctx;
     return RT_OK;
+    });
 }
 
 void rt_context_destroy(rt_context* ctx)
@@ -307,6 +331,7 @@ void rt_context_destroy(rt_context* ctx)
         b->release();
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : ctx->chunk_ev) (void)hipEventDestroy(ev);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -315,15 +340,17 @@ void* rt_context_stream(rt_context* ctx) { return ctx ? (void*)ctx->stream : nul
 
 int rt_context_synchronize(rt_context* ctx)
 {
+    return guarded([&]() -> int {
     if (!ctx) return fail(RT_ERR_INVALID, "ctx is NULL");
     int rc = use_device(ctx);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     unsigned long long v[2];
-    if ((rc = take_overflow_latch(v))) return rc;
-    if (v[0]) return fail(RT_ERR_LIMIT, "traversal stack overflow in an earlier call on this device");
-    if (v[1]) return fail(RT_ERR_LIMIT, "bounce/gather/photon queue overflow in an earlier call on this device");
+    if ((rc = take_overflow_latch(ctx, v))) return rc;
+    if (v[0]) return fail(RT_ERR_LIMIT, "traversal stack overflow in an earlier call on this context");
+    if (v[1]) return fail(RT_ERR_LIMIT, "bounce/gather/photon queue overflow in an earlier call on this context");
     return RT_OK;
+    });
 }
 
 void rt_default_params(rt_render_params* p)
@@ -365,80 +392,105 @@ void rt_camera_look_at(const double pos[3], const double look_at[3], rt_camera* 
 // ---------------------------------------------------------------- host scene
 int rt_scene_create(rt_scene** out)
 {
+    return guarded([&]() -> int {
     if (!out) return fail(RT_ERR_INVALID, "out is NULL");
     *out = new rt_scene();
     return RT_OK;
+    });
 }
 void rt_scene_destroy(rt_scene* s) { delete s; }
 int rt_scene_size(const rt_scene* s) { return s ? (int)s->s.objects.size() : 0; }
 
 int rt_scene_add_triangle(rt_scene* s, const double A[3], const double C[3], const double B[3], const double rgbs[4], float ior)
 {
+    return guarded([&]() -> int {
     if (!s || !A || !B || !C || !rgbs) return fail(RT_ERR_INVALID, "null argument");
     return s->s.add_triangle(A, C, B, rgbs, ior);
+    });
 }
 int rt_scene_set_normals(rt_scene* s, int obj, const double na[3], const double nc[3], const double nb[3])
 {
+    return guarded([&]() -> int {
     if (!s || !na || !nb || !nc) return fail(RT_ERR_INVALID, "null argument");
     return s->s.set_normals(obj, na, nc, nb) ? fail(RT_ERR_INVALID, "object %d is not a triangle", obj) : RT_OK;
+    });
 }
 int rt_scene_set_texture(rt_scene* s, int obj, const double ta[2], const double tc[2], const double tb[2], int use_texture, int map)
 {
+    return guarded([&]() -> int {
     if (!s || !ta || !tb || !tc) return fail(RT_ERR_INVALID, "null argument");
     return s->s.set_texture(obj, ta, tc, tb, use_texture, map) ? fail(RT_ERR_INVALID, "object %d is not a triangle or map %d unknown", obj, map)
                                                                  : RT_OK;
+    });
 }
 int rt_scene_add_sphere(rt_scene* s, const double center[3], double radius, const double rgbs[4], float ior)
 {
+    return guarded([&]() -> int {
     if (!s || !center || !rgbs) return fail(RT_ERR_INVALID, "null argument");
     return s->s.add_sphere(center, radius, rgbs, ior);
+    });
 }
 int rt_scene_add_plane(rt_scene* s, const double normal[3], double distance, const double rgbs[4])
 {
+    return guarded([&]() -> int {
     if (!s || !normal || !rgbs) return fail(RT_ERR_INVALID, "null argument");
     return s->s.add_plane(normal, distance, rgbs);
+    });
 }
 int rt_scene_add_cornell_box(rt_scene* s, const double corner1[3], const double corner2[3])
 {
+    return guarded([&]() -> int {
     if (!s || !corner1 || !corner2) return fail(RT_ERR_INVALID, "null argument");
     s->s.add_cornell_box(corner1, corner2);
     return RT_OK;
+    });
 }
 int rt_scene_add_cube(rt_scene* s, const double corner1[3], const double corner2[3], const double rgbs[4])
 {
+    return guarded([&]() -> int {
     if (!s || !corner1 || !corner2 || !rgbs) return fail(RT_ERR_INVALID, "null argument");
     s->s.add_cube(corner1, corner2, rgbs);
     return RT_OK;
+    });
 }
 int rt_scene_load_obj(rt_scene* s, const char* path, const double rgbs[4], float ior, float xoff, float yoff, float zoff, int use_texture,
                       int map)
 {
+    return guarded([&]() -> int {
     if (!s || !path || !rgbs) return fail(RT_ERR_INVALID, "null argument");
     int rc = s->s.load_obj(path, rgbs, ior, xoff, yoff, zoff, use_texture, map);
     if (rc == -1) return fail(RT_ERR_IO, "cannot open %s", path);
     if (rc) return fail(RT_ERR_IO, "bad vertex index in %s", path);
     return RT_OK;
+    });
 }
 int rt_scene_add_texture_bmp(rt_scene* s, const char* path)
 {
+    return guarded([&]() -> int {
     if (!s || !path) return fail(RT_ERR_INVALID, "null argument");
     int rc = s->s.add_texture_bmp(path);
     return rc < 0 ? fail(RT_ERR_IO, "cannot read texture %s", path) : rc;
+    });
 }
 int rt_scene_add_texture_rgb(rt_scene* s, int x_res, int y_res, const double* rgb)
 {
+    return guarded([&]() -> int {
     if (!s) return fail(RT_ERR_INVALID, "null argument");
     int rc = s->s.add_texture_rgb(x_res, y_res, rgb);
     return rc < 0 ? fail(RT_ERR_INVALID, "bad texture") : rc;
+    });
 }
 int rt_scene_build_bvh(rt_scene* s)
 {
+    return guarded([&]() -> int {
     if (!s) return fail(RT_ERR_INVALID, "null argument");
     s->s.build_bvh();
     return RT_OK;
+    });
 }
 int rt_scene_bvh_dump(const rt_scene* s, int32_t* rec, int64_t* n_rec, double* boxes, int64_t* n_boxes)
 {
+    return guarded([&]() -> int {
     if (!s || !n_rec || !n_boxes) return fail(RT_ERR_INVALID, "null argument");
     if (!s->s.bvh.built) return fail(RT_ERR_STATE, "rt_scene_build_bvh has not been called");
     std::vector<int32_t> r;
@@ -452,11 +504,13 @@ int rt_scene_bvh_dump(const rt_scene* s, int32_t* rec, int64_t* n_rec, double* b
     *n_rec = (int64_t)r.size();
     *n_boxes = (int64_t)b.size() / 6;
     return RT_OK;
+    });
 }
 int rt_scene_bvh_depth(const rt_scene* s) { return (s && s->s.bvh.built) ? s->s.bvh.depth : -1; }
 
 int rt_scene_get_triangle(const rt_scene* s, int obj, double points[9], double normals[9], double uvs[6], int* flags)
 {
+    return guarded([&]() -> int {
     if (!s || obj < 0 || obj >= (int)s->s.objects.size()) return fail(RT_ERR_INVALID, "object %d out of range", obj);
     const rth::Object& o = s->s.objects[obj];
     if (o.sh.kind != rtf::PRIM_TRI) return fail(RT_ERR_INVALID, "object %d is not a triangle", obj);
@@ -467,10 +521,12 @@ int rt_scene_get_triangle(const rt_scene* s, int obj, double points[9], double n
     if (uvs) { uvs[0] = o.sh.tA[0]; uvs[1] = o.sh.tA[1]; uvs[2] = o.sh.tB[0]; uvs[3] = o.sh.tB[1]; uvs[4] = o.sh.tC[0]; uvs[5] = o.sh.tC[1]; }
     if (flags) *flags = (o.sh.has_normal ? 1 : 0) | (o.has_uv ? 2 : 0);
     return RT_OK;
+    });
 }
 
 int rt_scene_emit_photons(rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy)
 {
+    return guarded([&]() -> int {
     if (!s || !light_pos || n_emit < 0) return fail(RT_ERR_INVALID, "bad argument");
     if (!s->s.bvh.built) return fail(RT_ERR_STATE, "rt_scene_build_bvh has not been called");
     rth::EmitParams ep;
@@ -478,6 +534,7 @@ int rt_scene_emit_photons(rt_scene* s, int64_t n_emit, const double light_pos[3]
     ep.accuracy = accuracy;
     rth::emit_photons(s->s, n_emit, light_pos, seed, ep, s->photons[0], s->photons[1]);
     return RT_OK;
+    });
 }
 }  // extern "C"
 namespace {
@@ -497,7 +554,6 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
     const unsigned long long cap_v = ((unsigned long long)batch * 4 + rtq::SHARDS - 1) / rtq::SHARDS + 16384;
     if ((rc = ctx->hits_a.reserve(cap_s * rtq::SHARDS * sizeof(rte::PhotonOut)))) return rc;
     if ((rc = ctx->hits_b.reserve(cap_v * rtq::SHARDS * sizeof(rte::PhotonOut)))) return rc;
-    if ((rc = ctx->counters.reserve(sizeof(rte::EmitCounters)))) return rc;
     rte::ShadeTables sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     rte::EmitCounters* ctr = (rte::EmitCounters*)ctx->counters.p;
     uint64_t rays = 0;
@@ -519,8 +575,8 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
         rte::EmitCounters hc;
         HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (hc.overflow_stack) return overflow_error("traversal stack overflow");
-        if (hc.overflow_queue) return overflow_error("photon queue overflow");
+        if (hc.overflow_stack) return overflow_error(ctx, "traversal stack overflow");
+        if (hc.overflow_queue) return overflow_error(ctx, "photon queue overflow");
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         ms_total += ms;
@@ -625,6 +681,7 @@ extern "C" {
 int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy,
                               rt_stats* stats)
 {
+    return guarded([&]() -> int {
     if (!ctx || !s || !light_pos || n_emit < 0 || bounce < 0 || bounce > 7) return fail(RT_ERR_INVALID, "bad argument");
     if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
     if ((int64_t)s->s.objects.size() != ctx->n_objects) return fail(RT_ERR_STATE, "the scene is not the one uploaded to this context");
@@ -653,11 +710,13 @@ int rt_scene_emit_photons_gpu(rt_context* ctx, rt_scene* s, int64_t n_emit, cons
         }
     }
     return RT_OK;
+    });
 }
 
 int rt_emit_photon_maps_dev(rt_context* ctx, int64_t n_emit, const double light_pos[3], uint32_t seed, int bounce, double accuracy, int64_t counts[2],
                             rt_stats* stats)
 {
+    return guarded([&]() -> int {
     if (!ctx || !light_pos || n_emit < 0 || bounce < 0 || bounce > 7) return fail(RT_ERR_INVALID, "bad argument");
     if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
     int rc;
@@ -710,10 +769,12 @@ int rt_emit_photon_maps_dev(rt_context* ctx, int64_t n_emit, const double light_
         stats->kernel_ms = est.trace_kernel_ms + ms;     // emission + ordering + both tree builds
     }
     return RT_OK;
+    });
 }
 
 int rt_photons_upload_dev_build(rt_context* ctx, int which, int64_t n, const double* photons)
 {
+    return guarded([&]() -> int {
     if (!ctx || (which != 0 && which != 1) || n < 0 || (n > 0 && !photons)) return fail(RT_ERR_INVALID, "bad argument");
     if (n >= (1ll << 31)) return fail(RT_ERR_LIMIT, "photon count %lld exceeds 2^31", (long long)n);
     int rc = use_device(ctx);
@@ -724,12 +785,14 @@ int rt_photons_upload_dev_build(rt_context* ctx, int which, int64_t n, const dou
     if ((rc = build_photon_map_dev(ctx, which, n, (const double*)ctx->ph_src[which].p, 9))) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));     // the caller's buffer is free again
     return RT_OK;
+    });
 }
 
 int64_t rt_photon_map_size(const rt_context* ctx, int which) { return (ctx && (which == 0 || which == 1)) ? (int64_t)ctx->pm[which].n : -1; }
 
 int rt_photon_map_get(rt_context* ctx, int which, double* photons)
 {
+    return guarded([&]() -> int {
     if (!ctx || (which != 0 && which != 1) || !photons) return fail(RT_ERR_INVALID, "bad argument");
     if (ctx->ph_src_n[which] != ctx->pm[which].n) return fail(RT_ERR_STATE, "photon map %d was not built on the device", which);
     int rc = use_device(ctx);
@@ -738,15 +801,18 @@ int rt_photon_map_get(rt_context* ctx, int which, double* photons)
         HIP_TRY(hipMemcpyAsync(photons, ctx->ph_src[which].p, (size_t)ctx->ph_src_n[which] * 72, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RT_OK;
+    });
 }
 
 int64_t rt_scene_photon_count(const rt_scene* s, int which) { return (s && (which == 0 || which == 1)) ? (int64_t)s->photons[which].size() : -1; }
 int rt_scene_photons_get(const rt_scene* s, int which, double* photons)
 {
+    return guarded([&]() -> int {
     if (!s || !photons || (which != 0 && which != 1)) return fail(RT_ERR_INVALID, "bad argument");
     static_assert(sizeof(rth::PhotonRec) == 9 * sizeof(double), "PhotonRec is 9 doubles");
     memcpy(photons, s->photons[which].data(), s->photons[which].size() * sizeof(rth::PhotonRec));
     return RT_OK;
+    });
 }
 void rt_scene_photons_clear(rt_scene* s)
 {
@@ -786,6 +852,7 @@ extern "C" {
 
 int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
 {
+    return guarded([&]() -> int {
     if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
     const rth::Scene& s = scene->s;
     if (!s.bvh.built) return fail(RT_ERR_STATE, "rt_scene_build_bvh has not been called");
@@ -824,10 +891,12 @@ int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
     ctx->n_objects = (int)s.objects.size();
     ctx->has_scene = true;
     return RT_OK;
+    });
 }
 
 int rt_scene_upload_lbvh(rt_context* ctx, const rt_scene* scene, double* build_ms)
 {
+    return guarded([&]() -> int {
     if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
     const rth::Scene& s = scene->s;
     int rc = use_device(ctx);
@@ -948,10 +1017,12 @@ int rt_scene_upload_lbvh(rt_context* ctx, const rt_scene* scene, double* build_m
     ctx->n_objects = (int)s.objects.size();
     ctx->has_scene = true;
     return RT_OK;
+    });
 }
 
 int rt_trace_closest_dev(rt_context* ctx, int precision, int64_t n, const double* d_org, const double* d_dir, double* d_dist, int32_t* d_ids)
 {
+    return guarded([&]() -> int {
     if (!ctx || !d_org || !d_dir || !d_dist || !d_ids) return fail(RT_ERR_INVALID, "null argument");
     if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
     if (n <= 0) return RT_OK;
@@ -960,10 +1031,12 @@ int rt_trace_closest_dev(rt_context* ctx, int precision, int64_t n, const double
     if (precision == RT_F64) return launch_batch<double>(ctx, n, d_org, d_dir, d_dist, d_ids);
     if (precision == RT_F32) return launch_batch<float>(ctx, n, d_org, d_dir, d_dist, d_ids);
     return fail(RT_ERR_INVALID, "precision %d", precision);
+    });
 }
 
 int rt_trace_closest(rt_context* ctx, int precision, int64_t n, const double* org, const double* dir, double* dist, int32_t* ids)
 {
+    return guarded([&]() -> int {
     if (!ctx || !org || !dir || !dist || !ids) return fail(RT_ERR_INVALID, "null argument");
     if (!ctx->has_scene) return fail(RT_ERR_STATE, "no scene uploaded");
     if (n <= 0) return RT_OK;
@@ -987,13 +1060,15 @@ int rt_trace_closest(rt_context* ctx, int precision, int64_t n, const double* or
     HIP_TRY(hipMemcpyAsync(ids, ctx->st_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     rtk::TraceCounters c;
     if ((rc = read_counters(ctx, &c))) return rc;
-    if (c.overflow) return overflow_error("traversal stack overflow");
+    if (c.overflow) return overflow_error(ctx, "traversal stack overflow");
     return RT_OK;
+    });
 }
 
 int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end, int32_t* d_ids,
                          double* d_t, int32_t* d_shadow_ids, rt_stats* stats)
 {
+    return guarded([&]() -> int {
     if (!ctx || !cam || !d_ids) return fail(RT_ERR_INVALID, "null argument");
     int rc = check_params(p);
     if (rc) return rc;
@@ -1020,7 +1095,7 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
     if (stats) {
         rtk::TraceCounters c;
         if ((rc = read_counters(ctx, &c))) return rc;
-        if (c.overflow) return overflow_error("traversal stack overflow");
+        if (c.overflow) return overflow_error(ctx, "traversal stack overflow");
         memset(stats, 0, sizeof(*stats));
         stats->primary_rays = (uint64_t)p->width * (uint64_t)(row_end - row_begin);
         stats->shadow_rays = c.shadow;
@@ -1032,11 +1107,13 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
         stats->trace_kernel_ms = ms;
     }
     return RT_OK;
+    });
 }
 
 int rt_trace_primary(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end, int32_t* ids, double* t,
                      int32_t* shadow_ids, rt_stats* stats)
 {
+    return guarded([&]() -> int {
     if (!ctx || !ids) return fail(RT_ERR_INVALID, "null argument");
     int rc = check_params(p);
     if (rc) return rc;
@@ -1057,11 +1134,13 @@ int rt_trace_primary(rt_context* ctx, const rt_camera* cam, const rt_render_para
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (stats) *stats = local;
     return RT_OK;
+    });
 }
 
 // ---------------------------------------------------------------- photon map
 int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photons)
 {
+    return guarded([&]() -> int {
     if (!ctx || (which != 0 && which != 1) || n < 0 || (n > 0 && !photons)) return fail(RT_ERR_INVALID, "bad argument");
     if (n >= (1ll << 31)) return fail(RT_ERR_LIMIT, "photon count %lld exceeds 2^31", (long long)n);
     int rc = use_device(ctx);
@@ -1080,6 +1159,7 @@ int rt_photons_upload(rt_context* ctx, int which, int64_t n, const double* photo
     ctx->pm[which].n = n;
     ctx->ph_src_n[which] = -1;
     return RT_OK;
+    });
 }
 
 }  // extern "C"
@@ -1141,26 +1221,32 @@ extern "C" {
 
 int rt_knn_radius(rt_context* ctx, int which, int k, double max_dist, int64_t n, const double* centers, int32_t* counts, double* r2)
 {
+    return guarded([&]() -> int {
     if (!ctx || !centers || (which != 0 && which != 1) || n < 0) return fail(RT_ERR_INVALID, "bad argument");
     if (n == 0) return RT_OK;
     return knn_launch(ctx, which, k, max_dist, 16, n, centers, nullptr, nullptr, counts, r2, nullptr);
+    });
 }
 
 int rt_knn_query(rt_context* ctx, int which, int k, double max_dist, int64_t n, const double* centers, int32_t* idx, int32_t* counts)
 {
+    return guarded([&]() -> int {
     if (!ctx || !centers || !idx || (which != 0 && which != 1) || n < 0) return fail(RT_ERR_INVALID, "bad argument");
     if (n == 0) return RT_OK;
     return knn_launch(ctx, which, k, max_dist, 16, n, centers, nullptr, nullptr, counts, nullptr, nullptr, idx);
+    });
 }
 
 int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal, const double* color,
                     double* rgb, int32_t* counts)
 {
+    return guarded([&]() -> int {
     if (!ctx || !pos || !normal || !color || !rgb || n < 0) return fail(RT_ERR_INVALID, "bad argument");
     int rc = check_params(p);
     if (rc) return rc;
     if (n == 0) return RT_OK;
     return knn_launch(ctx, 0, p->photon_use, p->photon_dist, p->photon_num, n, pos, normal, color, counts, nullptr, rgb);
+    });
 }
 
 // ---------------------------------------------------------------- full pixel path
@@ -1175,6 +1261,7 @@ extern "C" {
 int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal, const double* color,
                             double* rgb)
 {
+    return guarded([&]() -> int {
     if (!ctx || !pos || !normal || !color || !rgb || n < 0) return fail(RT_ERR_INVALID, "bad argument");
     int rc = check_params(p);
     if (rc) return rc;
@@ -1214,6 +1301,7 @@ int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t 
     HIP_TRY(hipMemcpyAsync(rgb, ctx->acc.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));    // also: `recs` and `n_slots` die at return
     return RT_OK;
+    });
 }
 }  // extern "C"
 
@@ -1289,7 +1377,8 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
 }
 
 template <class R>
-int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, double* d_acc, rtr::RenderCounters* host_ctr)
+int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, double* d_acc, rtr::RenderCounters* host_ctr,
+                 hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     const int rows = a.row_end - a.row_begin;
     const unsigned long long samples = (unsigned long long)a.width * rows * (a.dof_samples > 1 ? a.aadepth * a.aadepth * a.dof_samples : a.aadepth);
@@ -1314,7 +1403,7 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     if ((rc = trace_geometry<R>(ctx, ctx->n_nodes, &g, 16))) return rc;
     rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+    if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, ctx->stream));
     const bool tri_only = view<R>(ctx).tri_only;
     if (tri_only) {
         if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, true, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr, d_acc);
@@ -1326,7 +1415,7 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
         else rc = launch_render_levels<R, false, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr, d_acc);
     }
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(ctx->ev[3], ctx->stream));
+    if (ev_end) HIP_TRY(hipEventRecord(ev_end, ctx->stream));
     if (p->use_photon_map && (ctx->pm[0].n > 0 || ctx->pm[1].n > 0)) {
         rtg::GatherParams gp;
         gp.front_cap = gather_front_cap();
@@ -1349,6 +1438,7 @@ extern "C" {
 int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end, double* d_rgb,
                        uint8_t* d_bgr8, rt_stats* stats)
 {
+    return guarded([&]() -> int {
     if (!ctx || !cam) return fail(RT_ERR_INVALID, "null argument");
     int rc = check_params(p);
     if (rc) return rc;
@@ -1376,7 +1466,14 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     const long long per_pixel = p->dof_samples > 1 ? (long long)p->aadepth * p->aadepth * p->dof_samples : p->aadepth;
     int chunk_rows = (int)std::max<long long>(8, (max_samples / ((long long)p->width * per_pixel)) / 8 * 8);
     if ((long long)p->width * chunk_rows >= (1ll << 25)) return fail(RT_ERR_LIMIT, "width %d: a block of 8 rows exceeds 2^25 pixels", p->width);
-    std::vector<rtr::RenderCounters> hc((size_t)((row_end - row_begin + chunk_rows - 1) / chunk_rows));
+    const size_t n_chunks = (size_t)((row_end - row_begin + chunk_rows - 1) / chunk_rows);
+    std::vector<rtr::RenderCounters> hc(n_chunks);
+    if (stats)
+        while (ctx->chunk_ev.size() < 2 * n_chunks) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            ctx->chunk_ev.push_back(e);
+        }
     rt_stats total;
     memset(&total, 0, sizeof total);
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
@@ -1393,7 +1490,9 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
             acc = (double*)ctx->acc.p;
         }
         a.row_begin = r0; a.row_end = r1;
-        rc = p->precision == RT_F64 ? render_block<double>(ctx, a, p, acc, stats ? &hc[ci] : nullptr) : render_block<float>(ctx, a, p, acc, stats ? &hc[ci] : nullptr);
+        hipEvent_t eb = stats ? ctx->chunk_ev[2 * ci] : nullptr, ee = stats ? ctx->chunk_ev[2 * ci + 1] : nullptr;
+        rc = p->precision == RT_F64 ? render_block<double>(ctx, a, p, acc, stats ? &hc[ci] : nullptr, eb, ee)
+                                    : render_block<float>(ctx, a, p, acc, stats ? &hc[ci] : nullptr, eb, ee);
         if (rc) return rc;
         int threads = 256;
         hipLaunchKernelGGL(rtr::resolve_kernel, dim3((unsigned)((npx + threads - 1) / threads)), dim3(threads), 0, ctx->stream, (long long)npx, p->aadepth,
@@ -1405,8 +1504,8 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     if (stats) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         for (size_t i = 0; i < ci; i++) {
-            if (hc[i].overflow_stack) return overflow_error("traversal stack overflow");
-            if (hc[i].overflow_queue) return overflow_error("bounce/gather queue overflow");
+            if (hc[i].overflow_stack) return overflow_error(ctx, "traversal stack overflow");
+            if (hc[i].overflow_queue) return overflow_error(ctx, "bounce/gather queue overflow");
             total.secondary_rays += hc[i].secondary_rays;
             for (int sh = 0; sh < rtq::SHARDS; sh++) total.gather_queries += hc[i].gather.n[sh][1];
             total.gather_single += hc[i].n_redo;
@@ -1414,16 +1513,20 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         total.kernel_ms = ms;
-        HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));   // trace + shade kernels of the last chunk
-        total.trace_kernel_ms = ms;
+        for (size_t i = 0; i < ci; i++) {                            // trace + shade launches, summed over the row chunks
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->chunk_ev[2 * i], ctx->chunk_ev[2 * i + 1]));
+            total.trace_kernel_ms += ms;
+        }
         *stats = total;
     }
     return RT_OK;
+    });
 }
 
 int rt_render_rows(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end, double* rgb, uint8_t* bgr8,
                    rt_stats* stats)
 {
+    return guarded([&]() -> int {
     if (!ctx || !cam || (!rgb && !bgr8)) return fail(RT_ERR_INVALID, "null argument");
     int rc = check_params(p);
     if (rc) return rc;
@@ -1441,11 +1544,13 @@ int rt_render_rows(rt_context* ctx, const rt_camera* cam, const rt_render_params
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (stats) *stats = local;
     return RT_OK;
+    });
 }
 
 // ---------------------------------------------------------------- frame assembly over the GPUs of one process
 int rt_gather_rows(rt_context* const* ctxs, const void* const* d_parts, int n_parts, int band_rows, int height, size_t row_bytes, void* d_frame)
 {
+    return guarded([&]() -> int {
     if (!ctxs || !d_parts || !d_frame || n_parts < 1 || band_rows < 1 || height < 1 || row_bytes == 0) return fail(RT_ERR_INVALID, "bad argument");
     if (height % (band_rows * n_parts) != 0)
         return fail(RT_ERR_INVALID, "row interleave band_rows %d n_parts %d does not tile height %d", band_rows, n_parts, height);
@@ -1458,8 +1563,9 @@ int rt_gather_rows(rt_context* const* ctxs, const void* const* d_parts, int n_pa
         rt_context* c = ctxs[r];
         int rc = use_device(c);
         if (rc) return rc;
+        bool direct = true;
         if (c->device != dst_device) {
-            // direct xGMI copies where the devices can reach each other; the runtime stages the copy otherwise
+            // a direct xGMI copy where the source device can reach the frame's memory
             int can = 0;
             HIP_TRY(hipDeviceCanAccessPeer(&can, c->device, dst_device));
             if (can) {
@@ -1467,11 +1573,25 @@ int rt_gather_rows(rt_context* const* ctxs, const void* const* d_parts, int n_pa
                 if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
                 else if (e != hipSuccess) return fail(RT_ERR_HIP, "hipDeviceEnablePeerAccess(%d -> %d) failed: %s", c->device, dst_device, hipGetErrorString(e));
             }
+            direct = can != 0;
         }
         // band b of part r is band b * n_parts + r of the frame: one strided copy per part, in the order of the
         // stream that traced the part
-        HIP_TRY(hipMemcpy2DAsync((char*)d_frame + (size_t)r * band_bytes, band_bytes * n_parts, d_parts[r], band_bytes, band_bytes, n_bands, hipMemcpyDefault,
-                                 c->stream));
+        if (direct) {
+            HIP_TRY(hipMemcpy2DAsync((char*)d_frame + (size_t)r * band_bytes, band_bytes * n_parts, d_parts[r], band_bytes, band_bytes, n_bands, hipMemcpyDeviceToDevice,
+                                     c->stream));
+        } else {
+            // no peer access between the two devices: through pinned host memory (down on the part's stream, which waits for
+            // its kernels; up on the frame's device)
+            void* host = nullptr;
+            HIP_TRY(hipHostMalloc(&host, band_bytes * n_bands, hipHostMallocDefault));
+            hipError_t e = hipMemcpyAsync(host, d_parts[r], band_bytes * n_bands, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e == hipSuccess) e = hipSetDevice(dst_device);
+            if (e == hipSuccess) e = hipMemcpy2D((char*)d_frame + (size_t)r * band_bytes, band_bytes * n_parts, host, band_bytes, band_bytes, n_bands, hipMemcpyHostToDevice);
+            (void)hipHostFree(host);
+            if (e != hipSuccess) return fail(RT_ERR_HIP, "staged copy of part %d (device %d -> %d) failed: %s", r, c->device, dst_device, hipGetErrorString(e));
+        }
     }
     for (int r = 0; r < n_parts; r++) {
         int rc = use_device(ctxs[r]);
@@ -1479,20 +1599,25 @@ int rt_gather_rows(rt_context* const* ctxs, const void* const* d_parts, int n_pa
         HIP_TRY(hipStreamSynchronize(ctxs[r]->stream));
     }
     return use_device(ctxs[0]);
+    });
 }
 
 // ---------------------------------------------------------------- host I/O
 int rt_save_bmp(const char* path, int w, int h, int dpi, const double* rgb)
 {
+    return guarded([&]() -> int {
     if (!path || !rgb || w <= 0 || h <= 0) return fail(RT_ERR_INVALID, "bad argument");
     std::vector<uint8_t> bgr((size_t)w * h * 3);
     rth::quantize_bgr8((int64_t)w * h, rgb, bgr.data());
     return rth::save_bmp_bgr8(path, w, h, dpi, bgr.data()) ? fail(RT_ERR_IO, "cannot write %s", path) : RT_OK;
+    });
 }
 int rt_save_bmp_bgr8(const char* path, int w, int h, int dpi, const uint8_t* bgr)
 {
+    return guarded([&]() -> int {
     if (!path || !bgr || w <= 0 || h <= 0) return fail(RT_ERR_INVALID, "bad argument");
     return rth::save_bmp_bgr8(path, w, h, dpi, bgr) ? fail(RT_ERR_IO, "cannot write %s", path) : RT_OK;
+    });
 }
 
 }  // extern "C"

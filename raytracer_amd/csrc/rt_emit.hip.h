@@ -219,8 +219,8 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> 
             }
         }
     }
-    if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(0); }
-    if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(1); }
+    if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(ctr, 0); }
+    if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(ctr, 1); }
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if ((threadIdx.x & 63) == 0 && n_rays) atomicAdd(&ctr->rays, n_rays);
 }

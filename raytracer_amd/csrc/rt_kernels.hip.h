@@ -286,11 +286,16 @@ __device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, siz
 // real_size = 0 for TRAV_RETEST (no entry distances)
 inline size_t stack_lds_bytes(int cap, size_t real_size, int waves = WAVES_PER_BLOCK) { return (size_t)waves * cap * WAVE * (sizeof(uint32_t) + real_size); }
 
-// Overflow latch of this device: [0] traversal stack, [1] bounce / gather / photon queue.  Kernels raise it next to
-// the per-call counters; it is never cleared by a launch, so calls that do not wait for their kernels (no stats
-// requested) still get their overflow reported, by the next rt_context_synchronize on the device.
-__device__ unsigned long long g_overflow_latch[2];
-__device__ __forceinline__ void latch_overflow(int which) { atomicMax(&g_overflow_latch[which], 1ull); }
+// Overflow latch of a context: two words -- [0] traversal stack, [1] bounce / gather / photon queue -- at a fixed
+// offset behind the per-call counter block every kernel of the context gets (`counters` below is that block's base).
+// Kernels raise it next to the per-call counters; no launch clears it, so calls that do not wait for their
+// kernels (no stats requested) still get their overflow reported, by the next rt_context_synchronize of THAT context
+// (contexts sharing a device do not see each other's).
+constexpr size_t LATCH_OFFSET = 64 * 1024;
+__device__ __forceinline__ void latch_overflow(void* counters, int which)
+{
+    atomicMax(reinterpret_cast<unsigned long long*>(static_cast<char*>(counters) + LATCH_OFFSET) + which, 1ull);
+}
 
 // next: unused (kept for layout); overflow: stack-overflow flag; shadow: shadow rays traced; inner / prims: work of the counting build
 struct TraceCounters { unsigned long long next, overflow, shadow, inner, prims, pad[3]; };
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(BLOCK) void trace_batch_kernel(rtf::SceneView<R> sv
         ids[i] = id;
         if (id >= 0) dist_io[i] = (double)dist;
     }
-    if (overflow) { atomicMax(&ctr->overflow, 1ull); latch_overflow(0); }
+    if (overflow) { atomicMax(&ctr->overflow, 1ull); latch_overflow(ctr, 0); }
 }
 
 struct PrimaryArgs {
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
             }
         }
     }
-    if (overflow) { atomicMax(&ctr->overflow, 1ull); latch_overflow(0); }
+    if (overflow) { atomicMax(&ctr->overflow, 1ull); latch_overflow(ctr, 0); }
     if (a.shadow) {
         // one atomic per wave
         for (int off = 32; off > 0; off >>= 1) n_shadow += __shfl_down(n_shadow, off);

@@ -178,8 +178,8 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
                 push_hits(hits, &ctr->hits[1], shard_cap, want, rec, &ovf_queue);
             }
     }
-    if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(0); }
-    if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(1); }
+    if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(ctr, 0); }
+    if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(ctr, 1); }
 }
 
 // The ray queue in windows, too: the rays one shading wave spawns in one sample slot (one kind, one tile's
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
         }
         rtg::push_window(gq, &ctr->gather, shard_cap, want_g, g, &ovf_queue);
     }
-    if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(1); }
+    if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(ctr, 1); }
 }
 
 // Shoot for every queued ray of a level; hits become the next level's queue (main.cpp:190-199, 242-250).
@@ -407,8 +407,8 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
         }
         push_hits(out, &ctr->hits[level + 1], shard_cap, want, next, &ovf_queue);
     }
-    if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(0); }
-    if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(1); }
+    if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(ctr, 0); }
+    if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(ctr, 1); }
     for (int off = 32; off > 0; off >>= 1) n_secondary += __shfl_down(n_secondary, off);
     if (st.lane == 0 && n_secondary) atomicAdd(&ctr->secondary_rays, n_secondary);
 }

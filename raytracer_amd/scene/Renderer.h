@@ -65,16 +65,21 @@ public:
     // the pixel loop: pixels[y * width + x], y = 0 is the bottom BMP row (main.cpp:739,758).  With several GPUs
     // (RT_DEVICES) one host thread drives each -- the reference's thread fan-out, main.cpp:689-695,735-736 -- over
     // bands of 8 rows dealt round-robin (cost is uneven over the frame), or contiguous row blocks when the height does
-    // not divide into such bands.
-    rt_stats render(const Camera& cam, const rt_render_params& params, RGBType* pixels)
+    // not divide into such bands.  Returns RT_OK or the rt_status of the part that failed (rt_last_error() and
+    // last_error() then hold its message; `pixels` is incomplete); the reference's loop cannot fail, a GPU can.
+    int render(const Camera& cam, const rt_render_params& params, RGBType* pixels, rt_stats* stats = nullptr)
     {
         rt_camera c = cam.abi();
         const std::vector<rt_context*>& ctxs = rt::devices();
         const int n = (int)ctxs.size(), w = params.width, h = params.height;
         rt_stats st;
+        memset(&st, 0, sizeof st);
+        error.clear();
         if (n == 1) {
-            rt::check(rt_render_rows(ctxs[0], &c, &params, 0, h, &pixels[0].r, nullptr, &st), "rt_render_rows");
-            return st;
+            int rc = rt_render_rows(ctxs[0], &c, &params, 0, h, &pixels[0].r, nullptr, &st);
+            if (rc < 0) error = rt_last_error();
+            if (stats) *stats = st;
+            return rc;
         }
         const int band = 8;
         const bool bands = h % (band * n) == 0;
@@ -100,8 +105,8 @@ public:
         for (std::thread& t : threads) t.join();
         for (int r = 0; r < n; r++)
             if (status[(size_t)r] < 0) {
-                fprintf(stderr, "raytracer_amd: rt_render_rows on GPU %d of %d failed (%d): %s\n", r, n, status[(size_t)r], message[(size_t)r].c_str());
-                abort();
+                error = "GPU " + std::to_string(r) + " of " + std::to_string(n) + ": " + message[(size_t)r];
+                return status[(size_t)r];
             }
         if (bands)
             for (int r = 0; r < n; r++)
@@ -109,13 +114,19 @@ public:
                     const int y = ((yc / band) * n + r) * band + yc % band;
                     memcpy(&pixels[(size_t)y * (size_t)w].r, &part[(size_t)r][(size_t)yc * (size_t)w * 3], (size_t)w * 3 * sizeof(double));
                 }
-        memset(&st, 0, sizeof st);
         for (const rt_stats& s : part_st) {
             st.primary_rays += s.primary_rays; st.secondary_rays += s.secondary_rays; st.shadow_rays += s.shadow_rays;
             st.gather_queries += s.gather_queries; st.gather_single += s.gather_single;
             st.kernel_ms = s.kernel_ms > st.kernel_ms ? s.kernel_ms : st.kernel_ms;
             st.trace_kernel_ms = s.trace_kernel_ms > st.trace_kernel_ms ? s.trace_kernel_ms : st.trace_kernel_ms;
         }
-        return st;
+        if (stats) *stats = st;
+        return RT_OK;
     }
+
+    // message of the last failed render() of this object
+    const std::string& last_error() const { return error; }
+
+private:
+    std::string error;
 };

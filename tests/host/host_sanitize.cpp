@@ -3,6 +3,7 @@
 //   host_sanitize <mesh.obj> <tex.bmp> <out.bmp> <instances>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../raytracer_amd/csrc/host_photon.h"
@@ -43,6 +44,25 @@ int main(int argc, char** argv)
     std::vector<uint8_t> bgr(rgb.size());
     rth::quantize_bgr8(16 * 8, rgb.data(), bgr.data());
     if (rth::save_bmp_bgr8(argv[3], 16, 8, 72, bgr.data()) != 0) return 4;
+
+    // bitmap headers that lie about their size: a truncated file and one announcing 2^31-1 x 2^31-1 texels are refused
+    // before anything is allocated for them; the 16 x 8 file just written reads back
+    {
+        std::string good = argv[3], bad = good + ".bad";
+        if (s.add_texture_bmp(good.c_str()) < 0) return 7;
+        unsigned char header[54] = {'B', 'M'};
+        for (int huge = 0; huge < 2; huge++) {
+            const int w = huge ? 0x7fffffff : 64, h = huge ? 0x7fffffff : 64;
+            for (int i = 0; i < 4; i++) { header[18 + i] = (unsigned char)(w >> (8 * i)); header[22 + i] = (unsigned char)(h >> (8 * i)); }
+            FILE* f = fopen(bad.c_str(), "wb");
+            if (!f) return 8;
+            fwrite(header, 1, 54, f);
+            fwrite(bgr.data(), 1, 100, f);      // far fewer texels than announced
+            fclose(f);
+            if (s.add_texture_bmp(bad.c_str()) >= 0) return 9;
+        }
+        remove(bad.c_str());
+    }
     printf("objects %zu nodes %zu depth %d photons %zu nan-hit %d axis-hit %d\n", s.objects.size(), s.bvh.nodes.size(), s.bvh.depth, surface.size(), hit_nan, hit_axis);
     return hit_nan == -1 && hit_axis >= 0 ? 0 : 5;
 }

@@ -153,6 +153,8 @@ def test_ten_million_triangles_two_trees_one_image(gpu_ctx):
         assert hip.hipMemcpy(out.ctypes.data_as(ctypes.c_void_p), d, ctypes.c_size_t(h * w * 3), 2) == 0
         assert hip.hipFree(d) == 0
         return out, st_
+    # (photon_num only scales the radiance estimate, main.cpp:293: 160 instead of the emitted count lifts the frame
+    # out of the lowest 8-bit levels, so that the comparison of the two frames means something)
     light = (side * 0.5, c, c)
     (n_surface, _), _ = gpu_ctx.emit_photon_maps(2_000_000, light_pos=light, seed=7)
     assert n_surface > 100_000
@@ -160,7 +162,7 @@ def test_ten_million_triangles_two_trees_one_image(gpu_ctx):
     for tree in ("device", "reference"):
         if tree == "reference":
             gpu_ctx.upload(s)
-        p16 = rt.default_params(width=w, height=h, aadepth=4, photon_num=2_000_000, photon_use=50)
+        p16 = rt.default_params(width=w, height=h, aadepth=4, photon_num=160, photon_use=50)
         frame, st16 = render_bgr8(p16)
         assert st16.primary_rays == w * h * 4 and st16.secondary_rays == 0
         assert st16.gather_queries > 4 * 9000000
@@ -168,7 +170,7 @@ def test_ten_million_triangles_two_trees_one_image(gpu_ctx):
     differ = (frames[0] != frames[1]).any(-1).mean()
     assert differ < 1e-3, differ
     assert frames[1].max() > 50 and (frames[1].sum(-1) > 0).mean() > 0.05     # a lit frame
-    one = render_bgr8(rt.default_params(width=w, height=h, aadepth=1, photon_num=2_000_000, photon_use=50))[0].astype(np.int32)
+    one = render_bgr8(rt.default_params(width=w, height=h, aadepth=1, photon_num=160, photon_use=50))[0].astype(np.int32)
     sixteen = frames[1].astype(np.int32)
     # camera rays of aadepth 4 leave pixel (x, y) between the centres of pixels (x - 1 .. x + 1, y - 1 .. y + 1)
     interior = (one[1:-1, 1:-1].sum(-1) > 0) & (one[:-2, 1:-1].sum(-1) > 0) & (one[2:, 1:-1].sum(-1) > 0) & (one[1:-1, :-2].sum(-1) > 0) & (one[1:-1, 2:].sum(-1) > 0)

@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import CAM, DATA, ROOT, build_scene
+from conftest import CAM, DATA, ROOT, build_scene, golden
 from oracle.bindings import Oracle
 
 pytestmark = pytest.mark.gpu
@@ -61,3 +61,23 @@ def test_scene_program_split_over_several_contexts(tmp_path, devices):
         outs.append(np.fromfile(out, np.uint8))
     assert len(outs[0]) == 54 + w * h * 3 and outs[0][54:].max() > 0
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_scene_program_subsurface_two_trees(tmp_path):
+    """main.cpp:724-728 as written there -- `new KDTree(photons)` then `new KDTree(volumePhotons)`, both through the
+    one-argument constructor: the second tree must become the volume map, not replace the surface map.  The frame is the
+    one the compiled reference's getColorAt produced for the subsurface teapot (RMSE-level parity: the march's step
+    lengths come from another generator)."""
+    exe = os.path.join(ROOT, "examples", "main_scene")
+    assert os.path.exists(exe), "examples/main_scene missing: run __graft_entry__.build()"
+    g = golden("render_sss_64.npz")
+    out = str(tmp_path / "sss.bmp")
+    r = subprocess.run([exe, os.path.join(DATA, "teapot_normal.obj"), out, "64", "64", "20000", "12345", "-1.0", "1.3", "-0.7", "0.9", "0.7", "0.6", "50000"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120, env=dict(os.environ, RT_DEVICE_TREE="0"))
+    assert r.returncode == 0, r.stdout
+    assert f"photons {len(g['photons'])} + {len(g['volume_photons'])}" in r.stdout, r.stdout
+    got = np.fromfile(out, np.uint8)[54:].reshape(64, 64, 3)[..., ::-1].astype(np.int32)
+    ref = np.floor(np.clip(g["rgb"], 0, 1) * 255).astype(np.int32)
+    within = (np.abs(got - ref).max(-1) <= 1).mean()
+    rmse = float(np.sqrt(((got - ref) ** 2).mean()))
+    assert within >= 0.99 and rmse <= 1.0, (within, rmse)

@@ -141,6 +141,39 @@ def test_gather_rows_assembles_the_frame_on_the_device(scenes):
         rt.gather_rows(ctxs, d_parts, band, h + 1, w * 4, d_frame)          # does not tile: refused before any copy
 
 
+def test_gather_rows_across_two_devices(scenes):
+    """The same assembly with the parts on two DIFFERENT GPUs (peer copies over xGMI, or the staged path where the
+    devices cannot reach each other).  Needs a box with at least two GPUs."""
+    import ctypes
+    from raytracer_amd import _lib
+    if _lib.lib.rt_device_count() < 2:
+        pytest.skip("one GPU on this box")
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+    n_parts, band = 2, 8
+    w, h = 200, band * n_parts * 4
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    ctxs = [rt.Context(0), rt.Context(1)]
+    for c in ctxs:
+        c.upload(scenes["teapot_normal"])
+    whole, _, _, _ = ctxs[0].trace_primary(cam, rt.default_params(width=w, height=h, shadow_rays=0))
+
+    def dmalloc(dev, n_bytes):
+        p = ctypes.c_void_p()
+        assert hip.hipSetDevice(dev) == 0 and hip.hipMalloc(ctypes.byref(p), ctypes.c_size_t(n_bytes)) == 0
+        return p
+    d_parts = [dmalloc(r, (h // n_parts) * w * 4) for r in range(n_parts)]
+    d_frame = dmalloc(0, h * w * 4)
+    assert hip.hipMemset(d_frame, 0xFF, ctypes.c_size_t(h * w * 4)) == 0
+    for r, c in enumerate(ctxs):
+        p = rt.default_params(width=w, height=h, shadow_rays=0, band_rows=band, n_parts=n_parts, part=r)
+        c.trace_primary_dev(cam, p, (0, h // n_parts), d_parts[r], None, None, stats=False)
+    rt.gather_rows(ctxs, d_parts, band, h, w * 4, d_frame)
+    got = np.zeros(h * w, np.int32)
+    assert hip.hipSetDevice(0) == 0
+    assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), d_frame, ctypes.c_size_t(h * w * 4), 2) == 0
+    assert eq(got, whole)
+
+
 def test_shadow_rays_match_oracle(gpu_ctx, scenes):
     """Occlusion rays (extension) go through the same Shoot semantics with a bounded range."""
     gpu_ctx.upload(scenes["teapot_normal"])
