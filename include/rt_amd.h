@@ -242,6 +242,18 @@ int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const
 int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t n, const double* pos, const double* normal,
                             const double* color, double* rgb);
 
+/* No counterpart in the reference.  rt_knn_estimate_grouped for callers that cannot allocate device memory -- code
+ * under HIP graph capture, tight serving loops, harnesses that forbid it: requests and results live in the caller's
+ * device buffers (d_pos / d_normal / d_color: n x 3 doubles; d_rgb: n x 3 doubles out), and every byte of working
+ * memory (request queue, hand-over list, counters) is a fixed array inside the library, about 7.7 MB on each GPU it
+ * runs on, held until the process ends.  The call makes no hipMalloc / hipFree; it is enqueued on the context's
+ * stream and not synchronised.  n <= RT_NOALLOC_MAX_REQUESTS, more is refused with RT_ERR_LIMIT.  Every call on a
+ * GPU shares that GPU's array: calls that overlap in time on one GPU (two contexts, two streams) race; calls on
+ * one context's stream are ordered and safe. */
+#define RT_NOALLOC_MAX_REQUESTS 65536
+int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int64_t n, const double* d_pos, const double* d_normal,
+                                const double* d_color, double* d_rgb);
+
 /* ---- device: full pixel path ------------------------------------------------------------- */
 /* The pixel loop of main.cpp:735-861 for rows [row_begin,row_end): primary rays, BVH::Shoot,
  * getColorAt (main.cpp:158-392: reflection / refraction bounce queue + photon gather) and the

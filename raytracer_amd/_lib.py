@@ -93,6 +93,7 @@ PROTOTYPES = {
     "rt_knn_query": (c_i, [vp, c_i, c_i, c_d, c_i64, P(c_d), P(c_i32), P(c_i32)]),
     "rt_knn_estimate": (c_i, [vp, P(RenderParams), c_i64, P(c_d), P(c_d), P(c_d), P(c_d), P(c_i32)]),
     "rt_knn_estimate_grouped": (c_i, [vp, P(RenderParams), c_i64, P(c_d), P(c_d), P(c_d), P(c_d)]),
+    "rt_knn_estimate_dev_noalloc": (c_i, [vp, P(RenderParams), c_i64, vp, vp, vp, vp]),
     "rt_render_rows_dev": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, vp, vp, P(Stats)]),
     "rt_render_rows": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, P(c_d), P(c_u8), P(Stats)]),
     "rt_gather_rows": (c_i, [P(vp), P(vp), c_i, c_i, c_i, ctypes.c_size_t, vp]),

@@ -90,6 +90,19 @@ int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
 
 }  // namespace
 
+// ---- working memory of the entry point that allocates nothing (rt_knn_estimate_dev_noalloc) -----------------------
+// One fixed array per GPU the library runs on, held until the process ends: [counter block + overflow latch]
+// [request queue: RT_NOALLOC_MAX_REQUESTS records] [list of the requests the group kernel hands on].
+constexpr size_t NA_COUNTERS = rtk::LATCH_OFFSET + 256;
+constexpr size_t NA_QUEUE = (size_t)RT_NOALLOC_MAX_REQUESTS * sizeof(rtg::GatherRec);
+constexpr size_t NA_REDO = (size_t)RT_NOALLOC_MAX_REQUESTS * sizeof(uint32_t);
+static_assert(RT_NOALLOC_MAX_REQUESTS % 64 == 0 && NA_QUEUE % 256 == 0, "the queue is whole windows and the list behind it stays aligned");
+static __device__ __align__(256) unsigned char scratch[NA_COUNTERS + NA_QUEUE + NA_REDO];
+// `scratch` is a host-side stand-in here, not a device address: host code uses the address hipGetSymbolAddress
+// gave for it on the device in question (every GPU holds its own copy of the array at its own address).
+constexpr int NA_MAX_DEVICES = 64;
+static unsigned char* g_scratch_at[NA_MAX_DEVICES];
+
 struct rt_scene {
     rth::Scene s;
     std::vector<rth::PhotonRec> photons[2];   // 0 surface, 1 volume
@@ -304,6 +317,17 @@ int rt_context_create(int device, rt_context** out)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return fail(RT_ERR_NO_DEVICE, "cannot create a stream on device %d", device);
+    }
+    // where this device keeps its copy of the fixed working array (once per device, with that device current)
+    if (device < NA_MAX_DEVICES && !g_scratch_at[device]) {
+        void* at = nullptr;
+        hipError_t se = hipGetSymbolAddress(&at, HIP_SYMBOL(scratch));
+        if (se != hipSuccess || !at) {
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(se));
+        }
+        g_scratch_at[device] = (unsigned char*)at;
     }
     for (auto& ev : ctx->ev)
         if (hipEventCreate(&ev) != hipSuccess) { delete ctx; return fail(RT_ERR_HIP, "hipEventCreate failed"); }
@@ -1254,7 +1278,7 @@ int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const
 
 namespace {
 int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
-                  unsigned long long* n_redo, unsigned long long* next_gather, const rtg::GatherParams& gp, double* d_acc);
+                  unsigned long long* n_redo, unsigned long long* next_gather, const rtg::GatherParams& gp, double* d_acc, uint32_t* d_redo, bool may_profile = true);
 }
 extern "C" {
 
@@ -1296,7 +1320,7 @@ int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t 
     gp.photon_num = (double)p->photon_num;
     gp.seed = 12345u;
     if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp,
-                            (double*)ctx->acc.p)))
+                            (double*)ctx->acc.p, (uint32_t*)ctx->redo.p)))
         return rc;
     HIP_TRY(hipMemcpyAsync(rgb, ctx->acc.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));    // also: `recs` and `n_slots` die at return
@@ -1306,19 +1330,79 @@ int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t 
 }  // extern "C"
 
 namespace {
+// Requests from device arrays (n x 3 doubles each) into windows of 64 queue records, as a shading wave would queue
+// them; the output doubles as the accumulator and starts at zero; one thread notes the queue's fill.
+__global__ void pack_requests_kernel(long long n, long long slots, const double* __restrict__ pos, const double* __restrict__ nrm,
+                                     const double* __restrict__ col, rtg::GatherRec* __restrict__ recs, rtq::Counts* cnt, double* __restrict__ rgb)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slots) return;
+    rtg::GatherRec g;
+    for (int c = 0; c < 3; c++) { g.pos[c] = 0; g.normal[c] = 0; g.color[c] = 0; g.march[c] = 0; }
+    g.weight = 0; g.pixel = 0; g.flags = 0;
+    if (i < n) {
+        for (int c = 0; c < 3; c++) { g.pos[c] = pos[3 * i + c]; g.normal[c] = nrm[3 * i + c]; g.color[c] = col[3 * i + c]; rgb[3 * i + c] = 0.0; }
+        g.weight = 1.0;
+        g.pixel = (uint32_t)i;
+        if (i % 64 == 0) g.flags = (uint32_t)(n - i < 64 ? n - i : 64) << rtg::GATHER_COUNT_SHIFT;
+    }
+    recs[i] = g;
+    if (i == 0) cnt->n[0][0] = (unsigned long long)slots;
+}
+}  // namespace
+
+extern "C" {
+int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int64_t n, const double* d_pos, const double* d_normal,
+                                const double* d_color, double* d_rgb)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !d_pos || !d_normal || !d_color || !d_rgb || n < 0) return fail(RT_ERR_INVALID, "bad argument");
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (p->photon_use < 1 || p->photon_use > rtg::MAX_K) return fail(RT_ERR_LIMIT, "photon_use %d outside [1,%d]", p->photon_use, rtg::MAX_K);
+    if (n > RT_NOALLOC_MAX_REQUESTS)
+        return fail(RT_ERR_LIMIT, "%lld requests exceed the %d this entry point has working memory for (split the batch, or use rt_knn_estimate_grouped)",
+                    (long long)n, RT_NOALLOC_MAX_REQUESTS);
+    if (n == 0) return RT_OK;
+    if (ctx->device >= NA_MAX_DEVICES || !g_scratch_at[ctx->device]) return fail(RT_ERR_STATE, "no working array on device %d", ctx->device);
+    if ((rc = use_device(ctx))) return rc;
+    unsigned char* const base = g_scratch_at[ctx->device];          // the device address, never the symbol's name
+    rtr::RenderCounters* ctr = (rtr::RenderCounters*)base;
+    rtg::GatherRec* recs = (rtg::GatherRec*)(base + NA_COUNTERS);
+    uint32_t* redo = (uint32_t*)(base + NA_COUNTERS + NA_QUEUE);
+    const long long slots = (n + 63) / 64 * 64;
+    // the array keeps the last call's contents: counters (queue fill, draw counters, hand-over count) start at zero
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
+    const int T = 256;
+    hipLaunchKernelGGL(pack_requests_kernel, dim3((unsigned)((slots + T - 1) / T)), dim3(T), 0, ctx->stream, (long long)n, slots, d_pos, d_normal, d_color, recs,
+                       &ctr->gather, d_rgb);
+    HIP_TRY(hipGetLastError());
+    rtg::GatherParams gp;
+    gp.front_cap = gather_front_cap();
+    gp.k = p->photon_use;
+    gp.r2 = (float)(p->photon_dist * p->photon_dist);
+    gp.norm = (double)(p->photon_num / 16) * 3.1415926;
+    gp.photon_num = (double)p->photon_num;
+    gp.seed = 12345u;
+    return launch_gather(ctx, recs, &ctr->gather, (unsigned long long)slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp, d_rgb, redo, false);
+    });
+}
+}  // extern "C"
+
+namespace {
 
 // The gather over a queue of request windows: the group kernel, then the per-request kernel for what it
 // left.  RT_GATHER_MODE=query hands every request to the per-request kernel (comparison runs).
 int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
-                  unsigned long long* n_redo, unsigned long long* next_gather, const rtg::GatherParams& gp, double* d_acc)
+                  unsigned long long* n_redo, unsigned long long* next_gather, const rtg::GatherParams& gp, double* d_acc, uint32_t* d_redo, bool may_profile)
 {
     const char* mode = getenv("RT_GATHER_MODE");
     // RT_GATHER_PROF=1: per-phase cycle totals of the group kernel, printed to stderr (development aid)
-    const bool prof = getenv("RT_GATHER_PROF") != nullptr;
+    const bool prof = may_profile && getenv("RT_GATHER_PROF") != nullptr;      // (the cycle accounting allocates its table)
     int rc;
     if (prof && (rc = ctx->st_aux.reserve(rtg::TP_SLOTS * 8))) return rc;
     if (prof) HIP_TRY(hipMemsetAsync(ctx->st_aux.p, 0, rtg::TP_SLOTS * 8, ctx->stream));
-    rtg::TileArgs ta{recs, cnt, shard_cap, next_window, (uint32_t*)ctx->redo.p, n_redo, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
+    rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
                      prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
     hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gp, d_acc);
     HIP_TRY(hipGetLastError());
@@ -1332,7 +1416,7 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
                 gp.k, v[rtg::TP_WINDOWS], v[rtg::TP_ROUNDS], v[rtg::TP_LANES] / nr, v[rtg::TP_STEPS] / nr, v[rtg::TP_KTH] / nr, v[rtg::TP_WALK] / nr,
                 v[rtg::TP_HIST] / nr, v[rtg::TP_CRIT] / nr, v[rtg::TP_RANK] / nr, v[rtg::TP_SUM] / nr);
     }
-    hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, (const uint32_t*)ctx->redo.p,
+    hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, (const uint32_t*)d_redo,
                        (const unsigned long long*)n_redo, next_gather, gp, d_acc);
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -1424,7 +1508,8 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
         gp.norm = (double)(p->photon_num / 16) * 3.1415926;
         gp.photon_num = (double)p->photon_num;
         gp.seed = p->rng_seed;
-        if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, shard_cap, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp, d_acc)))
+        if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, shard_cap, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp, d_acc,
+                                (uint32_t*)ctx->redo.p)))
             return rc;
     }
     if (host_ctr) HIP_TRY(hipMemcpyAsync(host_ctr, ctr, sizeof(*host_ctr), hipMemcpyDeviceToHost, ctx->stream));
