@@ -67,7 +67,9 @@ typedef struct rt_render_params {
     int32_t head_quirk;       /* 1: recurse with the *old* hit object as HEAD does (main.cpp:198,249) */
     int32_t use_photon_map;   /* 0: diffuse hits shade black (no gather)                         */
     int32_t precision;        /* rt_precision of traversal + shading                             */
-    int32_t shadow_rays;      /* extension (not in the reference): one occlusion ray per primary hit toward light_pos */
+    int32_t shadow_rays;      /* extension (not in the reference): 1 = one occlusion ray per primary hit toward light_pos, the occluder's id (-1: lit, -2: no
+                               * primary hit) written to d_shadow_ids; 2 = the same ray, and with d_shadow_ids NULL an occluded hit gets bit 30 set in its d_ids entry
+                               * (one word per pixel to move between GPUs) */
     int32_t count_work;       /* 1: also count inner-node visits and primitive tests (slower instrumented kernel) */
     /* Row interleave for multi-GPU tiling: with band_rows > 0 the call covers only the bands
      * b with b % n_parts == part (band b = image rows [b*band_rows, (b+1)*band_rows)); row_begin /

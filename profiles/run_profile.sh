@@ -3,7 +3,7 @@
 #   bash profiles/run_profile.sh <tag>
 # 1. kernel trace + stats of the default bench command, 2. separate PMC passes (never combined with tracing).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT

@@ -54,7 +54,7 @@ for k in {k for (k, c) in means}:
         if wc and gui:
             traffic[prec + "_waves_per_simd"] = round(wc * 4 / 1024 / (gui / 8), 3)
 if traffic:
-    traffic["_source"] = f"profiles/{tag}_pmc.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch of trace_primary_kernel"
+    traffic["source"] = f"profiles/{tag}_pmc.csv: (2 x FETCH_SIZE + WRITE_SIZE) KB per launch of trace_primary_kernel"
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 print(open(os.path.join(dst, f"{tag}_pmc.csv")).read())
 print(traffic)

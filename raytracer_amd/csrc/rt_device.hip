@@ -1107,7 +1107,7 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
         a.light[i] = p->light_pos[i];
     }
     a.width = p->width; a.height = p->height; a.row_begin = row_begin; a.row_end = row_end;
-    a.shadow = p->shadow_rays ? 1 : 0;
+    a.shadow = p->shadow_rays == 2 ? 2 : (p->shadow_rays ? 1 : 0);
     a.band_rows = p->band_rows; a.n_parts = p->n_parts; a.part = p->part;
     if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));      // (timing events only for a caller that reads them)
     if (p->count_work)
@@ -1423,7 +1423,7 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
 }
 
 // the three traversal kernels of the render path for one (R, TRI_ONLY, MODE) choice
-template <class R, bool TRI_ONLY, int MODE>
+template <class R, bool TRI_ONLY, int MODE, bool COUNT = false>
 int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceGeom& g, int levels, unsigned long long shard_cap,
                          rtr::RenderCounters* ctr, double* d_acc)
 {
@@ -1432,7 +1432,10 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int wpb = g.threads / 64;
     const dim3 grid((unsigned)rtk::tile_grid_blocks((a.width + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth));
-    if (a.dof_samples > 1)
+    if (COUNT)
+        hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE, false, COUNT>), grid, dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
+                           (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
+    else if (a.dof_samples > 1)
         hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE, true>), grid, dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
                            (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
     else
@@ -1451,7 +1454,7 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
                            (rtg::GatherRec*)ctx->gq.p, shard_cap, ctr);
         HIP_TRY(hipGetLastError());
         if (!last) {
-            hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
+            hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE, COUNT>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
                                (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes);
             HIP_TRY(hipGetLastError());
         }
@@ -1489,15 +1492,21 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
     if (ev_begin) HIP_TRY(hipEventRecord(ev_begin, ctx->stream));
     const bool tri_only = view<R>(ctx).tri_only;
+    // (the instrumented kernels exist for the double instantiation without depth of field, which is what measurements run)
+    const bool count = p->count_work && sizeof(R) == sizeof(double) && a.dof_samples <= 1;
+#define RT_LEVELS(TRI, MODE)                                                                                                  \
+    (count ? launch_render_levels<double, TRI, MODE, true>(ctx, a, g, levels, shard_cap, ctr, d_acc)                           \
+           : launch_render_levels<R, TRI, MODE, false>(ctx, a, g, levels, shard_cap, ctr, d_acc))
     if (tri_only) {
-        if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, true, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr, d_acc);
-        else if (g.mode == rtk::TRAV_RETEST) rc = launch_render_levels<R, true, rtk::TRAV_RETEST>(ctx, a, g, levels, shard_cap, ctr, d_acc);
-        else rc = launch_render_levels<R, true, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr, d_acc);
+        if (g.mode == rtk::TRAV_NODES) rc = RT_LEVELS(true, rtk::TRAV_NODES);
+        else if (g.mode == rtk::TRAV_RETEST) rc = RT_LEVELS(true, rtk::TRAV_RETEST);
+        else rc = RT_LEVELS(true, rtk::TRAV_PLAIN);
     } else {
-        if (g.mode == rtk::TRAV_NODES) rc = launch_render_levels<R, false, rtk::TRAV_NODES>(ctx, a, g, levels, shard_cap, ctr, d_acc);
-        else if (g.mode == rtk::TRAV_RETEST) rc = launch_render_levels<R, false, rtk::TRAV_RETEST>(ctx, a, g, levels, shard_cap, ctr, d_acc);
-        else rc = launch_render_levels<R, false, rtk::TRAV_PLAIN>(ctx, a, g, levels, shard_cap, ctr, d_acc);
+        if (g.mode == rtk::TRAV_NODES) rc = RT_LEVELS(false, rtk::TRAV_NODES);
+        else if (g.mode == rtk::TRAV_RETEST) rc = RT_LEVELS(false, rtk::TRAV_RETEST);
+        else rc = RT_LEVELS(false, rtk::TRAV_PLAIN);
     }
+#undef RT_LEVELS
     if (rc) return rc;
     if (ev_end) HIP_TRY(hipEventRecord(ev_end, ctx->stream));
     if (p->use_photon_map && (ctx->pm[0].n > 0 || ctx->pm[1].n > 0)) {
@@ -1594,6 +1603,8 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
             total.secondary_rays += hc[i].secondary_rays;
             for (int sh = 0; sh < rtq::SHARDS; sh++) total.gather_queries += hc[i].gather.n[sh][1];
             total.gather_single += hc[i].n_redo;
+            total.inner_visits += hc[i].work_inner;
+            total.prim_tests += hc[i].work_prims;
         }
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));

@@ -322,6 +322,8 @@ __global__ __launch_bounds__(BLOCK) void trace_batch_kernel(rtf::SceneView<R> sv
     if (overflow) { atomicMax(&ctr->overflow, 1ull); latch_overflow(ctr, 0); }
 }
 
+// shadow == 2 and no shadow-id buffer: an occluded hit gets this bit set in its id (ids stay below 2^27, see rt_flat.h)
+constexpr int SHADOWED_BIT = 1 << 30;
 struct PrimaryArgs {
     double cam_pos[3], cam_dir[3], cam_right[3], cam_down[3];
     double light[3];
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
                     n_shadow++;
                 }
                 if (shadow_ids) shadow_ids[px] = sid;
+                else if (a.shadow == 2 && sid >= 0) ids[px] = id | SHADOWED_BIT;      // folded form: one word per pixel
             }
         }
     }

@@ -82,7 +82,7 @@ struct RenderCounters {
     unsigned long long next_gather;     // draw counter of the per-request gather kernel
     unsigned long long next_window;     // draw counter of the group gather kernel
     unsigned long long n_redo;          // requests the group kernel left to the per-request kernel
-    unsigned long long pad[2];
+    unsigned long long work_inner, work_prims;   // inner-node visits and primitive tests (counting instantiations only)
 };
 
 struct ShadeData {
@@ -111,7 +111,7 @@ __device__ __forceinline__ int rtk_wave_max(int v)
 
 // DOF (depth of field compiled in) is a template parameter: its sample loops around the traversal cost the kernel 60
 // registers (147 instead of 87 in f64), and the reference's default build has no depth of field (main.cpp:35).
-template <class R, bool TRI_ONLY, int MODE, bool DOF>
+template <class R, bool TRI_ONLY, int MODE, bool DOF, bool COUNT = false>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::SceneView<R> sv, RenderArgs a, HitRec* __restrict__ hits,
                                                                        unsigned long long shard_cap, RenderCounters* ctr, int cap, int n_nodes,
                                                                        double* __restrict__ acc)
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
     LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0;
+    rtk::WorkCount wc;
     const int rows = a.row_end - a.row_begin;
     const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
     // one 8x8 tile and one of its aadepth sample columns per wave (the waves of a tile are neighbours in a block,
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
                     R o[3] = {(R)org.x, (R)org.y, (R)org.z};
                     R d[3] = {(R)dj.x, (R)dj.y, (R)dj.z};
                     R dist = R(1e9);
-                    int id = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack);
+                    int id = rtk::trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack, &wc);
                     if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
                         double t = (double)dist;
                         // the jittered origin, but the un-jittered direction (main.cpp:821-822)
@@ -180,6 +181,10 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
     }
     if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(ctr, 0); }
     if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(ctr, 1); }
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { wc.inner += __shfl_down(wc.inner, off); wc.prims += __shfl_down(wc.prims, off); }
+        if (st.lane == 0) { atomicAdd(&ctr->work_inner, wc.inner); atomicAdd(&ctr->work_prims, wc.prims); }
+    }
 }
 
 // The ray queue in windows, too: the rays one shading wave spawns in one sample slot (one kind, one tile's
@@ -360,7 +365,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
 // Shoot for every queued ray of a level; hits become the next level's queue (main.cpp:190-199, 242-250).
 // (The draw loop around the traversal costs this kernel about 45 registers -- 144 instead of 100 in f64, three waves per
 // SIMD.  Holding it to 128 with amdgpu_waves_per_eu spills 12 of them and was measured slower on both test frames.)
-template <class R, bool TRI_ONLY, int MODE>
+template <class R, bool TRI_ONLY, int MODE, bool COUNT = false>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneView<R> sv, RenderArgs a, int level, const RayRec* __restrict__ rays,
                                                                     HitRec* __restrict__ out, unsigned long long shard_cap, RenderCounters* ctr,
                                                                     int cap, int n_nodes)
@@ -371,6 +376,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
     LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0, n_secondary = 0;
+    rtk::WorkCount wc;
     // secondary rays differ a lot in cost: chunks of 64 are drawn dynamically (per-shard draw counters)
     const rtq::Map map = rtq::map_units(&ctr->rays[level], shard_cap, WAVE);
     rtq::Drawer drawer = rtq::drawer_init();
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
             R o[3] = {(R)ray.org[0], (R)ray.org[1], (R)ray.org[2]};
             R d[3] = {(R)ray.dir[0], (R)ray.dir[1], (R)ray.dir[2]};
             R dist = R(1e9);
-            int io = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack);
+            int io = rtk::trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack, &wc);
             n_secondary++;
             double t = (double)dist;
             bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:193,245
@@ -411,6 +417,10 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
     if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(ctr, 1); }
     for (int off = 32; off > 0; off >>= 1) n_secondary += __shfl_down(n_secondary, off);
     if (st.lane == 0 && n_secondary) atomicAdd(&ctr->secondary_rays, n_secondary);
+    if (COUNT) {
+        for (int off = 32; off > 0; off >>= 1) { wc.inner += __shfl_down(wc.inner, off); wc.prims += __shfl_down(wc.prims, off); }
+        if (st.lane == 0) { atomicAdd(&ctr->work_inner, wc.inner); atomicAdd(&ctr->work_prims, wc.prims); }
+    }
 }
 
 // Pixel average (main.cpp:853-859), clip (Color.h:39-57; a no-op after per-sample clipping) and the
