@@ -599,6 +599,7 @@ struct GatherParams {
     int front_cap;    // frontier entries in use (<= FRONT; smaller values only to test the serial walk)
     double photon_num;   // PHOTONMUM as a double: the volume normaliser divides in floating point (main.cpp:332)
     uint32_t seed;       // of the march's step lengths (main.cpp:374)
+    float opt_range = 0.3f;   // group form: widest relative range around the centre's k-th distance searched for a neighbour's (>= 1: the rigorous range)
 };
 
 // reduce a double over the wave (all lanes get lane 0's total after the final shuffle)
@@ -611,6 +612,31 @@ __device__ __forceinline__ float wave_max(float v)
 {
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off));
     return __shfl(v, 0);
+}
+
+// One photon's share of the radiance estimate (main.cpp:271-286) without the colours: |cosine| * weight.
+//   weight = 0.918 * (1 - (1 - e^(-1.953 * d2 / (2 * maxDistSqr))) / (1 - e^-1.953)),  e = 2.71828    (main.cpp:279)
+//          = A + B * 2^(c2 * d2)
+//   cosine = normal . (-photon direction)                                                              (main.cpp:281-284)
+// The reference evaluates both in double and rounds each to float before multiplying them; here they are evaluated
+// in float throughout (a few units in the last place of a float apart; the sums they enter are compared at 8-bit
+// resolution).  Both forms of the gather use this one function, so they add up the same terms.
+struct TermCoef { float c2, A, B; };
+__device__ __forceinline__ TermCoef term_coef(float maxDistSqr)
+{
+    const double ln_base = 0.999999327347282;              // ln 2.71828
+    const double inv_denom = 1.0 / (1 - exp(-1.953 * ln_base));
+    TermCoef t;
+    t.c2 = (float)(-1.953 * ln_base * 1.4426950408889634 / (2 * (double)maxDistSqr));
+    t.A = (float)(0.918 * (1 - inv_denom));
+    t.B = (float)(0.918 * inv_denom);
+    return t;
+}
+__device__ __forceinline__ float photon_term(const TermCoef& t, float d2, float nx, float ny, float nz, float ux, float uy, float uz)
+{
+    const float weight = t.A + t.B * __builtin_amdgcn_exp2f(t.c2 * d2);
+    const float cosine = nx * ux + ny * uy + nz * uz;        // of the angle to the photon's direction; the sign drops out below
+    return fabsf(cosine) * weight;
 }
 
 // Radiance estimate over the gathered set (main.cpp:262-295), before the final clip.
@@ -626,11 +652,8 @@ __device__ void estimate_raw(const PhotonMapView& pm, int count, const double* n
     for (int j = lane; j < count; j += WAVE) m = fmaxf(m, L.key[j]);
     const float maxDistSqr = wave_max(m);          // distance of the farthest returned photon (main.cpp:266-267)
     *max_d2 = maxDistSqr;
-    // 2.71828^x evaluated as exp(x * ln 2.71828)
-    const double ln_base = 0.999999327347282;
-    const double denom = 1 - exp(-1.953 * ln_base);
-    // the two loop-invariant divisors of main.cpp:279 as reciprocals (the weight is rounded to float anyway)
-    const double inv_denom = 1.0 / denom, inv_2max = 1.0 / (2 * (double)maxDistSqr);
+    const TermCoef tc = term_coef(maxDistSqr);
+    const float nx = (float)nrm[0], ny = (float)nrm[1], nz = (float)nrm[2];
     double s0 = 0, s1 = 0, s2 = 0;
     constexpr int UNR = 4;       // photons per lane whose records are fetched together
     for (int base = 0; base < count; base += UNR * WAVE) {
@@ -649,23 +672,16 @@ __device__ void estimate_raw(const PhotonMapView& pm, int count, const double* n
 #pragma unroll
         for (int u = 0; u < UNR; u++) {
             if (valid[u]) {
-                float distanceSqr = dsq[u];
-                // gaussian filter, main.cpp:279 (float result of a double expression)
-                // the exponential itself in single precision: the weight is a float in the reference and enters a
-                // sum that is compared at 8-bit resolution
-                float weight = (float)(0.918 * (1 - (1 - (double)__expf((float)(((-1.953 * (distanceSqr)) * inv_2max) * ln_base))) * inv_denom));
-                float cosine = (float)(nrm[0] * (-(double)a[u][3]) + nrm[1] * (-(double)a[u][4]) + nrm[2] * (-(double)a[u][5]));   // main.cpp:281-283
-                if (cosine < 0) cosine = -cosine;
-                double sc = (double)(cosine * weight);
-                s0 += (col[0] * (double)a[u][0]) * sc;        // main.cpp:286
-                s1 += (col[1] * (double)a[u][1]) * sc;
-                s2 += (col[2] * (double)a[u][2]) * sc;
+                const float sc = photon_term(tc, dsq[u], nx, ny, nz, a[u][3], a[u][4], a[u][5]);
+                s0 += (double)(a[u][0] * sc);             // main.cpp:286 without the hit colour, multiplied in below
+                s1 += (double)(a[u][1] * sc);
+                s2 += (double)(a[u][2] * sc);
             }
         }
     }
     s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     double scale = 1.0 / (norm * maxDistSqr);      // main.cpp:293
-    rgb[0] = s0 * scale; rgb[1] = s1 * scale; rgb[2] = s2 * scale;
+    rgb[0] = col[0] * s0 * scale; rgb[1] = col[1] * s1 * scale; rgb[2] = col[2] * s2 * scale;
 }
 
 __device__ __forceinline__ void clip3(double* v)   // Color::clip, Color.h:39-57

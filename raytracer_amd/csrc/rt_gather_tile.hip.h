@@ -74,7 +74,7 @@ struct TileArgs {
     int all_redo;                    // nonzero: hand every request to the per-query kernel (comparison runs)
     unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
 };
-enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_SLOTS };
+enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_N_HIST, TP_N_CRIT, TP_N_SUM, TP_SUM_ANY, TP_SUM_PAIRS, TP_SLOTS };
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // two photons per packed instruction
 
@@ -175,23 +175,43 @@ __device__ __attribute__((noinline)) int group_walk(PhotonMapView pm, float glx,
     return n_leaf | (n_piv << 16);
 }
 
-// squared distances from (qx, qy, qz) to photons j and j + 1 of a step (held by lanes j, j + 1 of p); the
-// operation order per photon is that of the per-request kernel, so the values are the same floats
-__device__ __forceinline__ f2 pair_d2(const float4& p, int j, float qx, float qy, float qz)
+// The photons of a step are handed from the lanes that fetched them to every lane through LDS: each lane writes its
+// photon's coordinates (x[64], y[64], z[64]; a sum pass also power and direction), then all lanes read the same
+// addresses -- a broadcast read, which costs one LDS instruction per four photons and component where a
+// lane-to-scalar move costs one vector instruction per photon and component.  The staging area lies over the
+// frontier arrays of the tree walks (f_lo, f_hi, f_d2: 3 KB, contiguous), which no pass uses.
+static_assert(offsetof(WaveLds, f_hi) == offsetof(WaveLds, f_lo) + FRONT * 4 && offsetof(WaveLds, f_d2) == offsetof(WaveLds, f_hi) + FRONT * 4 && FRONT * 12 >= WAVE * 9 * 4,
+              "the staging area of the passes lies over the three frontier arrays");
+__device__ __forceinline__ float* stage_xyz() { return reinterpret_cast<float*>(g_L.f_lo); }          // x[64] y[64] z[64]
+__device__ __forceinline__ float* stage_aux() { return reinterpret_cast<float*>(g_L.f_lo) + 3 * WAVE; } // [64][6]: power rgb, direction xyz
+__device__ __forceinline__ void stage_put(const float4& p, int lane)
 {
-    const f2 xs = {bcast(p.x, j), bcast(p.x, j + 1)}, ys = {bcast(p.y, j), bcast(p.y, j + 1)}, zs = {bcast(p.z, j), bcast(p.z, j + 1)};
-    const f2 dx = f2{qx, qx} - xs, dy = f2{qy, qy} - ys, dz = f2{qz, qz} - zs;
-    return dx * dx + dy * dy + dz * dz;
+    float* s = stage_xyz();
+    __builtin_amdgcn_wave_barrier();       // (the reads of the step before are done: LDS operations of a wave complete in order)
+    s[lane] = p.x; s[WAVE + lane] = p.y; s[2 * WAVE + lane] = p.z;
+    __builtin_amdgcn_wave_barrier();
 }
+
+struct D2x4 { f2 a, b; };      // squared distances to photons j .. j + 3
+// squared distances from (qx, qy, qz) to photons j .. j + 3 of the staged step (j a multiple of 4); the operation
+// order per photon is that of the per-request kernel, so the values are the same floats
+__device__ __forceinline__ D2x4 quad_d2(int j, float qx, float qy, float qz)
+{
+    const float* s = stage_xyz();
+    const float4 xs = *reinterpret_cast<const float4*>(s + j), ys = *reinterpret_cast<const float4*>(s + WAVE + j), zs = *reinterpret_cast<const float4*>(s + 2 * WAVE + j);
+    const f2 q_x = {qx, qx}, q_y = {qy, qy}, q_z = {qz, qz};
+    const f2 dxa = q_x - f2{xs.x, xs.y}, dya = q_y - f2{ys.x, ys.y}, dza = q_z - f2{zs.x, zs.y};
+    const f2 dxb = q_x - f2{xs.z, xs.w}, dyb = q_y - f2{ys.z, ys.w}, dzb = q_z - f2{zs.z, zs.w};
+    return D2x4{dxa * dxa + dya * dya + dza * dza, dxb * dxb + dyb * dyb + dzb * dzb};
+}
+
+// Histogram bin of a squared distance: bin 0 holds everything below `lower` (distances the triangle inequality
+// already puts inside the set), bins 1 .. T_BINS - 2 are linear over [lower, bound), the last bin takes everything
+// from `bound` on (and the filler photons of a short step), so no photon needs a comparison with the bound.
+// Monotone in d2.  scale = shell_scale(bound, lower).
+__device__ __forceinline__ float shell_scale(float bound, float lower) { return ((float)(T_BINS - 2) * 0.999999f) / (bound - lower); }
 __device__ __forceinline__ f2 shell_pos(f2 d2, float lower, float scale) { return (d2 - f2{lower, lower}) * f2{scale, scale} + f2{1.f, 1.f}; }
 __device__ __forceinline__ int shell_bin_of(float pos) { return (int)__builtin_amdgcn_fmed3f(pos, 0.f, (float)(T_BINS - 1)); }
-
-// Histogram bin of a squared distance: bin 0 holds everything below `lower` (distances the triangle
-// inequality already puts inside the set), bins 1.. are linear over [lower, bound).  Monotone in d2.
-__device__ __forceinline__ int shell_bin(float d2, float lower, float scale)
-{
-    return (int)__builtin_amdgcn_fmed3f((d2 - lower) * scale + 1.f, 0.f, (float)(T_BINS - 1));
-}
 
 // Copy to `dst` the leaves of `src` that some lane has to look at photon by photon: those with a photon
 // possibly at a squared distance in [lo_lim, hi_lim] from the lane's point (hi_lim < 0: the lane takes no
@@ -232,8 +252,8 @@ __device__ __attribute__((noinline)) int select_leaves(const float* __restrict__
 __device__ __forceinline__ uint32_t* lane_tables() { return reinterpret_cast<uint32_t*>(g_L.key); }   // [row][lane] over the candidate buffer
 
 // 3a: cell[bin][lane] = photons of the list whose squared distance to the lane's point falls into the bin
-__device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float bound, float lower,
-                                                    float scale, bool act, int n_leaf, int n_piv)
+__device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float lower, float scale,
+                                                    int n_leaf, int n_piv)
 {
     uint32_t* const cell = lane_tables();
     const int lane = lane_id();
@@ -242,54 +262,56 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
     __builtin_amdgcn_wave_barrier();
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
     uint32_t* const mine = cell + lane;
-    uint32_t* const sink = g_L.hist + lane;          // rejected photons count into a row nobody reads
-    const float lim = act ? bound : -1.f;
     int n = 0, at = 0, n_next = 0;
     float4 p = n_steps > 0 ? step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at) : float4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < n_steps; s++, n = n_next) {
-        // the next step's photons are on their way while this step's are used
-        const float4 p_now = p;
-        if (s + 1 < n_steps) p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
+        stage_put(p, lane);
         const int n_now = __builtin_amdgcn_readfirstlane(n);
+        // the next step's photons are on their way while this step's are used
+        if (s + 1 < n_steps) p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
         for (int j0 = 0; j0 < n_now; j0 += 8) {
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                const f2 d2 = pair_d2(p_now, j0 + u, qx, qy, qz);
-                const f2 at = shell_pos(d2, lower, scale);
-                atomicAdd(d2.x < lim ? mine + shell_bin_of(at.x) * WAVE : sink, 1u);
-                atomicAdd(d2.y < lim ? mine + shell_bin_of(at.y) * WAVE : sink, 1u);
+            for (int u = 0; u < 8; u += 4) {
+                const D2x4 d = quad_d2(j0 + u, qx, qy, qz);
+                const f2 at_a = shell_pos(d.a, lower, scale), at_b = shell_pos(d.b, lower, scale);
+                atomicAdd(mine + shell_bin_of(at_a.x) * WAVE, 1u);
+                atomicAdd(mine + shell_bin_of(at_a.y) * WAVE, 1u);
+                atomicAdd(mine + shell_bin_of(at_b.x) * WAVE, 1u);
+                atomicAdd(mine + shell_bin_of(at_b.y) * WAVE, 1u);
             }
         }
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-// 3b: cell[i][lane] = the i-th squared distance of the lane that falls into its bin `crit`; returns their number
-__device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float bound, float lower,
-                                                   float scale, bool some, int crit, int n_leaf, int n_piv)
+// 3b: cell[i][lane] = the i-th squared distance of the lane that falls into its bin `crit` (< 0: the lane takes
+// no part); returns their number
+__device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float lower, float scale, int crit,
+                                                   int n_leaf, int n_piv)
 {
     uint32_t* const cell = lane_tables();
     const int lane = lane_id();
     int cnt = 0;
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
-    const float lim = some ? bound : -1.f;
+    const float crit_f = (float)crit;
     int n = 0, at = 0, n_next = 0;
     float4 p = n_steps > 0 ? step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at) : float4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < n_steps; s++, n = n_next) {
-        // the next step's photons are on their way while this step's are used
-        const float4 p_now = p;
-        if (s + 1 < n_steps) p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
+        stage_put(p, lane);
         const int n_now = __builtin_amdgcn_readfirstlane(n);
-        for (int j0 = 0; j0 < n_now; j0 += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                const f2 d2 = pair_d2(p_now, j0 + u, qx, qy, qz);
-                const f2 at = shell_pos(d2, lower, scale);
-                const bool hit0 = d2.x < lim && shell_bin_of(at.x) == crit, hit1 = d2.y < lim && shell_bin_of(at.y) == crit;
-                if (__ballot(hit0 || hit1)) {           // rare: a few dozen photons per request
-                    if (hit0 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d2.x); cnt++; }
-                    if (hit1 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d2.y); cnt++; }
-                }
+        // the next step's photons are on their way while this step's are used
+        if (s + 1 < n_steps) p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
+        for (int j0 = 0; j0 < n_now; j0 += 4) {
+            const D2x4 d = quad_d2(j0, qx, qy, qz);
+            const f2 at_a = shell_pos(d.a, lower, scale), at_b = shell_pos(d.b, lower, scale);
+            // (the bin of a position is its integer part clamped to the table: compared as floats, one operation each)
+            const bool h0 = floorf(__builtin_amdgcn_fmed3f(at_a.x, 0.f, (float)(T_BINS - 1))) == crit_f, h1 = floorf(__builtin_amdgcn_fmed3f(at_a.y, 0.f, (float)(T_BINS - 1))) == crit_f;
+            const bool h2 = floorf(__builtin_amdgcn_fmed3f(at_b.x, 0.f, (float)(T_BINS - 1))) == crit_f, h3 = floorf(__builtin_amdgcn_fmed3f(at_b.y, 0.f, (float)(T_BINS - 1))) == crit_f;
+            if (__ballot(h0 || h1 || h2 || h3)) {           // rare: a few dozen photons per request
+                if (h0 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.x); cnt++; }
+                if (h1 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.y); cnt++; }
+                if (h2 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.x); cnt++; }
+                if (h3 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.y); cnt++; }
             }
         }
     }
@@ -299,15 +321,16 @@ __device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ po
 
 struct Sum3 { double s0, s1, s2; };
 
-// 3c: the sums of main.cpp:262-291 (power * cosine * weight per channel) over the photons with d2 < t_k and the
-// first want_eq with d2 == t_k
+// 3c: the sums of main.cpp:262-291 (power * |cosine| * weight per channel) over the photons with d2 < t_k and the
+// first want_eq with d2 == t_k.  TIES = false: every photon at exactly the k-th distance belongs to the set (the
+// caller has counted them), so the test is one comparison.
+template <bool TIES>
 __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ pos, const float* __restrict__ aux, const uint32_t* leaf, float qx, float qy, float qz, float t_k,
-                                                   int want_eq, bool some, double n0, double n1, double n2, int n_leaf, int n_piv)
+                                                   int want_eq, bool some, float nx, float ny, float nz, int n_leaf, int n_piv, unsigned long long* prof_any = nullptr)
 {
     const int lane = lane_id();
-    const double ln_base = 0.999999327347282;              // 2.71828^x evaluated as exp(x * ln 2.71828)
-    const double denom = 1 - exp(-1.953 * ln_base);
-    const double inv_denom = 1.0 / denom, inv_2max = 1.0 / (2 * (double)t_k);
+    unsigned long long c_any = 0, c_pairs = 0;
+    const TermCoef tc = term_coef(t_k);
     double s0 = 0, s1 = 0, s2 = 0;
     int eq_seen = 0;
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
@@ -320,40 +343,49 @@ __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ po
         const float* ax = aux + 6 * (size_t)at;
         b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
     }
+    float* const sa = stage_aux();
     for (int s = 0; s < n_steps; s++, n = n_next) {
+        stage_put(p, lane);
+        {
+            float* mine = sa + 6 * lane;
+            *reinterpret_cast<f2*>(mine) = f2{b0, b1}; *reinterpret_cast<f2*>(mine + 2) = f2{b2, b3}; *reinterpret_cast<f2*>(mine + 4) = f2{b4, b5};
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int n_now = __builtin_amdgcn_readfirstlane(n);
         // the next step's photons are on their way while this step's are used
-        const float4 p_now = p;
-        const float a0 = b0, a1 = b1, a2 = b2, a3 = b3, a4 = b4, a5 = b5;
         if (s + 1 < n_steps) {
             p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
             const float* ax = aux + 6 * (size_t)at;
             b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
         }
-        const int n_now = __builtin_amdgcn_readfirstlane(n);
         for (int j0 = 0; j0 < n_now; j0 += 4) {
-            const f2 d2a = pair_d2(p_now, j0, qx, qy, qz), d2b = pair_d2(p_now, j0 + 2, qx, qy, qz);
+            const D2x4 d = quad_d2(j0, qx, qy, qz);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int j = j0 + u;
-                const float d2 = u == 0 ? d2a.x : (u == 1 ? d2a.y : (u == 2 ? d2b.x : d2b.y));
-                bool in = d2 < lim;
-                if (d2 == lim) { in = eq_seen < want_eq; eq_seen++; }
-                if (__ballot(in)) {
-                    const float pr = bcast(a0, j), pg = bcast(a1, j), pb = bcast(a2, j), ux = bcast(a3, j), uy = bcast(a4, j), uz = bcast(a5, j);
+                const float d2 = u == 0 ? d.a.x : (u == 1 ? d.a.y : (u == 2 ? d.b.x : d.b.y));
+                bool in;
+                if (TIES) {
+                    in = d2 < lim;
+                    if (d2 == lim) { in = eq_seen < want_eq; eq_seen++; }
+                } else {
+                    in = d2 <= lim;
+                }
+                const unsigned long long m_in = __ballot(in);
+                if (prof_any) { c_any += m_in ? 1 : 0; c_pairs += __builtin_popcountll(m_in); }
+                if (m_in) {
+                    const f2 a01 = *reinterpret_cast<const f2*>(sa + 6 * j), a23 = *reinterpret_cast<const f2*>(sa + 6 * j + 2), a45 = *reinterpret_cast<const f2*>(sa + 6 * j + 4);
                     if (in) {
-                        // gaussian filter, main.cpp:279 (float result of a double expression; the exponential in single precision)
-                        float weight = (float)(0.918 * (1 - (1 - (double)__expf((float)(((-1.953 * (d2)) * inv_2max) * ln_base))) * inv_denom));
-                        float cosine = (float)(n0 * (-(double)ux) + n1 * (-(double)uy) + n2 * (-(double)uz));   // main.cpp:281-283
-                        if (cosine < 0) cosine = -cosine;
-                        const double sc = (double)(cosine * weight);
-                        s0 += (double)pr * sc;             // main.cpp:286 without the hit colour, which the caller multiplies in
-                        s1 += (double)pg * sc;
-                        s2 += (double)pb * sc;
+                        const float sc = photon_term(tc, d2, nx, ny, nz, a23.y, a45.x, a45.y);
+                        s0 += (double)(a01.x * sc);          // main.cpp:286 without the hit colour, which the caller multiplies in
+                        s1 += (double)(a01.y * sc);
+                        s2 += (double)(a23.x * sc);
                     }
                 }
             }
         }
     }
+    if (prof_any) { prof_any[0] += c_any; prof_any[1] += c_pairs; }
     return Sum3{s0, s1, s2};
 }
 
@@ -419,12 +451,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             float bound = gp.r2, lower = 0.f;
             if (r_c >= 0.f) {
                 act = todo && d_c <= r_c;                            // this round: the requests inside the centre's own ball
-                const float reach = r_c + d_c;
+                // r_k(q) lies within |q - q_c| of r_c (triangle inequality).  For a request far from the centre that
+                // range is wide -- up to four times the ball's area to search -- while the photon density, and with it
+                // r_k, changes little over a ball's width: such a request is given the range r_c * (1 -+ OPT_RANGE)
+                // instead.  Both ends are checked by the counts below (k photons inside the outer radius, fewer than k
+                // inside the inner one); a request that fails either goes to the per-request kernel.
+                const float dd = fminf(d_c, gp.opt_range * r_c);
+                const float reach = r_c + dd;
                 const float b = reach * reach * 1.001f + 1e-12f;      // slack for the rounding of the distances
                 if (b < bound) {
                     bound = b;
                     // and r_k(q) >= r_c - |q - q_c|: closer photons belong to the set whatever their order
-                    const float inner = fmaxf(r_c - d_c, 0.f);
+                    const float inner = fmaxf(r_c - dd, 0.f);
                     lower = inner * inner * 0.999f;
                 }
             }
@@ -450,17 +488,18 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             n_leaf = select_leaves(pm.leaf_box, g_T.leaf, g_T.leaf, qx, qy, qz, 0.f, act ? bound : -1.f, n_leaf, &n_out);
             pr[TP_ROUNDS]++; pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_leaf + (n_piv + WAVE - 1) / WAVE;
 
-            const float scale = ((float)(T_BINS - 1) - 0.001f) / (bound - lower);
+            const float scale = shell_scale(bound, lower);
             // ---- 3a. per-lane histogram of the squared distances below the lane's bound
             // leaves that lie inside every request's inner ball count as a whole; the others go photon by photon
             int n_inside;
             const int n_hist = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, act ? lower : 3.0e38f, act ? 3.0e38f : -1.f, n_leaf, &n_inside);
-            TILE_PROF(TP_HIST, pass_hist(pm.pos, g_T.part, qx, qy, qz, bound, lower, scale, act, n_hist, n_piv));
+            TILE_PROF(TP_HIST, pass_hist(pm.pos, g_T.part, qx, qy, qz, lower, scale, n_hist, n_piv));
+            pr[TP_N_HIST] += n_hist + (n_piv + WAVE - 1) / WAVE;
             if (act) cell[lane] += (uint32_t)n_inside;
             // the bin holding the lane's k-th smallest distance (or its largest, if fewer than k lie within the bound)
-            uint32_t total = 0;
+            uint32_t total = 0;                                   // (the last bin holds what lies beyond the bound)
 #pragma unroll 4
-            for (int b = 0; b < T_BINS; b++) total += cell[b * WAVE + lane];
+            for (int b = 0; b < T_BINS - 1; b++) total += cell[b * WAVE + lane];
             const uint32_t k_eff = total < (uint32_t)gp.k ? total : (uint32_t)gp.k;
             // a bound derived from the neighbour must contain k photons; if it somehow does not, the per-query kernel decides
             if (act && total < (uint32_t)gp.k && bound < gp.r2) { redo = true; act = false; }
@@ -469,7 +508,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             {
                 uint32_t cum = 0;
 #pragma unroll 4
-                for (int b = 0; b < T_BINS; b++) {
+                for (int b = 0; b < T_BINS - 1; b++) {
                     const uint32_t h = cell[b * WAVE + lane];
                     if (crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
                     cum += h;
@@ -485,7 +524,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             const float shell_lo = crit > 0 ? lower + (float)(crit - 1) / scale : 0.f, shell_hi = crit > 0 ? lower + (float)crit / scale : lower;
             const int n_crit = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, some ? shell_lo * 0.9999f : 3.0e38f, some ? shell_hi * 1.0001f : -1.f, n_leaf,
                                              &n_out);
-            TILE_PROF(TP_CRIT, cnt = pass_crit(pm.pos, g_T.part, qx, qy, qz, bound, lower, scale, some, crit, n_crit, n_piv));
+            TILE_PROF(TP_CRIT, cnt = pass_crit(pm.pos, g_T.part, qx, qy, qz, lower, scale, some ? crit : -1, n_crit, n_piv));
+            pr[TP_N_CRIT] += n_crit + (n_piv + WAVE - 1) / WAVE;
             const unsigned long long t_rank = ta.prof ? clock64() : 0ull;
             const int max_cnt = (int)wave_max_f((float)cnt);
             uint32_t t_bits = 0;
@@ -506,8 +546,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                 for (int u = 0; u < 8; u++)
                     if (i0 + u < cnt && rank[u] == need - 1) t_bits = e[u];
             }
-            int less = 0;
-            for (int j = 0; j < max_cnt; j++) less += (j < cnt && cell[j * WAVE + lane] < t_bits) ? 1 : 0;
+            int less = 0, equal = 0;
+            for (int j = 0; j < max_cnt; j++) {
+                const uint32_t o = cell[j * WAVE + lane];
+                less += (j < cnt && o < t_bits) ? 1 : 0;
+                equal += (j < cnt && o == t_bits) ? 1 : 0;
+            }
             const float t_k = __uint_as_float(t_bits);             // the k-th distance = maxDistSqr (main.cpp:266-267)
             const int want_eq = need - less;                       // photons at exactly that distance that belong to the set
             __builtin_amdgcn_wave_barrier();
@@ -516,7 +560,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             Sum3 sum;
             const unsigned long long t_sum = ta.prof ? clock64() : 0ull;
             n_leaf = select_leaves(pm.leaf_box, g_T.leaf, g_T.leaf, qx, qy, qz, 0.f, some ? t_k : -1.f, n_leaf, &n_out);      // the final balls are smaller than the bounds
-            sum = pass_sum(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, r.normal[0], r.normal[1], r.normal[2], n_leaf, n_piv);
+            // (photons at exactly the k-th distance: if some request must leave one of them out, the pass counts them as it goes)
+            if (__ballot(some && equal != want_eq))
+                sum = pass_sum<true>(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv,
+                                     ta.prof ? &pr[TP_SUM_ANY] : nullptr);
+            else
+                sum = pass_sum<false>(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv,
+                                      ta.prof ? &pr[TP_SUM_ANY] : nullptr);
+            pr[TP_N_SUM] += n_leaf + (n_piv + WAVE - 1) / WAVE;
             if (ta.prof) pr[TP_SUM] += clock64() - t_sum;
             if (some) {
                 const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
