@@ -91,6 +91,12 @@ __device__ __forceinline__ float wave_max_f(float v)
     return v;
 }
 
+// a pointer of unknown address space as one into global memory
+__device__ __forceinline__ const float __attribute__((address_space(1)))* as_global(const float* p)
+{
+    return (const float __attribute__((address_space(1)))*)p;
+}
+
 // Step s of the group's photon list: the tree position lane j reads (clamped to a valid one) and the
 // number of photons in the step (the same in every lane, returned as a scalar).
 __device__ __forceinline__ int step_index(const uint32_t* leaf, int s, int n_leaf, int n_piv, int lane, int& n)
@@ -106,14 +112,15 @@ __device__ __forceinline__ int step_index(const uint32_t* leaf, int s, int n_lea
     return (int)T.piv[first + (lane < n ? lane : n - 1)];
 }
 
-// the step's photons, lane j holding photon j; lanes beyond the step hold a point no ball reaches, so
-// the loops over a step need no bound checks
+// the step's photons, lane j holding photon j (lanes beyond the step re-read its last photon; stage_put replaces those
+// by a point no ball reaches, so the loops over a step need no bound checks)
 __device__ __forceinline__ float4 step_photons(const float4* __restrict__ pos, const uint32_t* leaf, int s, int n_leaf, int n_piv, int lane, int& n, int& at)
 {
     at = step_index(leaf, s, n_leaf, n_piv, lane, n);
-    float4 p = pos[at];
-    if (lane >= n) p.x = 1.0e18f;
-    return p;
+    // used only when it is staged, a step later: the fetch stays in flight meanwhile.  Read as GLOBAL memory: a pointer of
+    // unknown address space makes it a flat load, which every wait for an LDS read in the loops would wait for, too.
+    const float __attribute__((address_space(1)))* g = as_global(reinterpret_cast<const float*>(pos + at));
+    return float4{g[0], g[1], g[2], g[3]};
 }
 
 // k-th nearest distance around one point by the per-query machinery (< 0: fewer than k photons within the radius).
@@ -183,25 +190,29 @@ __device__ __attribute__((noinline)) int group_walk(PhotonMapView pm, float glx,
 static_assert(offsetof(WaveLds, f_hi) == offsetof(WaveLds, f_lo) + FRONT * 4 && offsetof(WaveLds, f_d2) == offsetof(WaveLds, f_hi) + FRONT * 4 && FRONT * 12 >= WAVE * 9 * 4,
               "the staging area of the passes lies over the three frontier arrays");
 __device__ __forceinline__ float* stage_xyz() { return reinterpret_cast<float*>(g_L.f_lo); }          // x[64] y[64] z[64]
-__device__ __forceinline__ float* stage_aux() { return reinterpret_cast<float*>(g_L.f_lo) + 3 * WAVE; } // [64][6]: power rgb, direction xyz
-__device__ __forceinline__ void stage_put(const float4& p, int lane)
+__device__ __forceinline__ float* stage_aux() { return reinterpret_cast<float*>(g_L.f_lo) + 3 * WAVE; } // [6][64]: power r, g, b, direction x, y, z
+__device__ __forceinline__ void stage_put(const float4& p, int lane, int n)
 {
     float* s = stage_xyz();
     __builtin_amdgcn_wave_barrier();       // (the reads of the step before are done: LDS operations of a wave complete in order)
-    s[lane] = p.x; s[WAVE + lane] = p.y; s[2 * WAVE + lane] = p.z;
+    s[lane] = lane < n ? p.x : 1.0e18f; s[WAVE + lane] = p.y; s[2 * WAVE + lane] = p.z;
     __builtin_amdgcn_wave_barrier();
 }
 
 struct D2x4 { f2 a, b; };      // squared distances to photons j .. j + 3
-// squared distances from (qx, qy, qz) to photons j .. j + 3 of the staged step (j a multiple of 4); the operation
-// order per photon is that of the per-request kernel, so the values are the same floats
-__device__ __forceinline__ D2x4 quad_d2(int j, float qx, float qy, float qz)
+struct Xyz4 { float4 x, y, z; };   // coordinates of photons j .. j + 3 of the staged step
+__device__ __forceinline__ Xyz4 quad_load(int j)          // j a multiple of 4, j + 3 < 64
 {
     const float* s = stage_xyz();
-    const float4 xs = *reinterpret_cast<const float4*>(s + j), ys = *reinterpret_cast<const float4*>(s + WAVE + j), zs = *reinterpret_cast<const float4*>(s + 2 * WAVE + j);
+    return Xyz4{*reinterpret_cast<const float4*>(s + j), *reinterpret_cast<const float4*>(s + WAVE + j), *reinterpret_cast<const float4*>(s + 2 * WAVE + j)};
+}
+// squared distances from (qx, qy, qz) to four photons; the operation order per photon is that of the per-request
+// kernel, so the values are the same floats
+__device__ __forceinline__ D2x4 quad_d2(const Xyz4& c, float qx, float qy, float qz)
+{
     const f2 q_x = {qx, qx}, q_y = {qy, qy}, q_z = {qz, qz};
-    const f2 dxa = q_x - f2{xs.x, xs.y}, dya = q_y - f2{ys.x, ys.y}, dza = q_z - f2{zs.x, zs.y};
-    const f2 dxb = q_x - f2{xs.z, xs.w}, dyb = q_y - f2{ys.z, ys.w}, dzb = q_z - f2{zs.z, zs.w};
+    const f2 dxa = q_x - f2{c.x.x, c.x.y}, dya = q_y - f2{c.y.x, c.y.y}, dza = q_z - f2{c.z.x, c.z.y};
+    const f2 dxb = q_x - f2{c.x.z, c.x.w}, dyb = q_y - f2{c.y.z, c.y.w}, dzb = q_z - f2{c.z.z, c.z.w};
     return D2x4{dxa * dxa + dya * dya + dza * dza, dxb * dxb + dyb * dyb + dzb * dzb};
 }
 
@@ -260,25 +271,27 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
 #pragma unroll 8
     for (int b = 0; b < T_BINS; b++) cell[b * WAVE + lane] = 0u;
     __builtin_amdgcn_wave_barrier();
+    n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);      // (the same in every lane: let the compiler know)
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
     uint32_t* const mine = cell + lane;
     int n = 0, at = 0, n_next = 0;
     float4 p = n_steps > 0 ? step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at) : float4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < n_steps; s++, n = n_next) {
-        stage_put(p, lane);
+        stage_put(p, lane, n);
         const int n_now = __builtin_amdgcn_readfirstlane(n);
         // the next step's photons are on their way while this step's are used
-        if (s + 1 < n_steps) p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
-        for (int j0 = 0; j0 < n_now; j0 += 8) {
-#pragma unroll
-            for (int u = 0; u < 8; u += 4) {
-                const D2x4 d = quad_d2(j0 + u, qx, qy, qz);
-                const f2 at_a = shell_pos(d.a, lower, scale), at_b = shell_pos(d.b, lower, scale);
-                atomicAdd(mine + shell_bin_of(at_a.x) * WAVE, 1u);
-                atomicAdd(mine + shell_bin_of(at_a.y) * WAVE, 1u);
-                atomicAdd(mine + shell_bin_of(at_b.x) * WAVE, 1u);
-                atomicAdd(mine + shell_bin_of(at_b.y) * WAVE, 1u);
-            }
+        p = step_photons(pos, leaf, s + 1 < n_steps ? s + 1 : s, n_leaf, n_piv, lane, n_next, at);      // (unconditional: a fetch inside a branch is waited for at its end)
+        // (the coordinates of the next four photons are read from LDS while the current four are binned)
+        Xyz4 c = quad_load(0);
+        for (int j0 = 0; j0 < n_now; j0 += 4) {
+            const Xyz4 c_now = c;
+            c = quad_load((j0 + 4) & (WAVE - 1));
+            const D2x4 d = quad_d2(c_now, qx, qy, qz);
+            const f2 at_a = shell_pos(d.a, lower, scale), at_b = shell_pos(d.b, lower, scale);
+            atomicAdd(mine + shell_bin_of(at_a.x) * WAVE, 1u);
+            atomicAdd(mine + shell_bin_of(at_a.y) * WAVE, 1u);
+            atomicAdd(mine + shell_bin_of(at_b.x) * WAVE, 1u);
+            atomicAdd(mine + shell_bin_of(at_b.y) * WAVE, 1u);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -292,17 +305,21 @@ __device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ po
     uint32_t* const cell = lane_tables();
     const int lane = lane_id();
     int cnt = 0;
+    n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);      // (the same in every lane: let the compiler know)
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
     const float crit_f = (float)crit;
     int n = 0, at = 0, n_next = 0;
     float4 p = n_steps > 0 ? step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at) : float4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < n_steps; s++, n = n_next) {
-        stage_put(p, lane);
+        stage_put(p, lane, n);
         const int n_now = __builtin_amdgcn_readfirstlane(n);
         // the next step's photons are on their way while this step's are used
-        if (s + 1 < n_steps) p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
+        p = step_photons(pos, leaf, s + 1 < n_steps ? s + 1 : s, n_leaf, n_piv, lane, n_next, at);      // (unconditional: a fetch inside a branch is waited for at its end)
+        Xyz4 c = quad_load(0);
         for (int j0 = 0; j0 < n_now; j0 += 4) {
-            const D2x4 d = quad_d2(j0, qx, qy, qz);
+            const Xyz4 c_now = c;
+            c = quad_load((j0 + 4) & (WAVE - 1));
+            const D2x4 d = quad_d2(c_now, qx, qy, qz);
             const f2 at_a = shell_pos(d.a, lower, scale), at_b = shell_pos(d.b, lower, scale);
             // (the bin of a position is its integer part clamped to the table: compared as floats, one operation each)
             const bool h0 = floorf(__builtin_amdgcn_fmed3f(at_a.x, 0.f, (float)(T_BINS - 1))) == crit_f, h1 = floorf(__builtin_amdgcn_fmed3f(at_a.y, 0.f, (float)(T_BINS - 1))) == crit_f;
@@ -326,13 +343,13 @@ struct Sum3 { double s0, s1, s2; };
 // caller has counted them), so the test is one comparison.
 template <bool TIES>
 __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ pos, const float* __restrict__ aux, const uint32_t* leaf, float qx, float qy, float qz, float t_k,
-                                                   int want_eq, bool some, float nx, float ny, float nz, int n_leaf, int n_piv, unsigned long long* prof_any = nullptr)
+                                                   int want_eq, bool some, float nx, float ny, float nz, int n_leaf, int n_piv)
 {
     const int lane = lane_id();
-    unsigned long long c_any = 0, c_pairs = 0;
     const TermCoef tc = term_coef(t_k);
     double s0 = 0, s1 = 0, s2 = 0;
     int eq_seen = 0;
+    n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);      // (the same in every lane: let the compiler know)
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
     const float lim = some ? t_k : -1.f;
     int n = 0, at = 0, n_next = 0;
@@ -340,29 +357,33 @@ __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ po
     float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
     if (n_steps > 0) {
         p = step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at);
-        const float* ax = aux + 6 * (size_t)at;
+        const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)at;
         b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
     }
     float* const sa = stage_aux();
     for (int s = 0; s < n_steps; s++, n = n_next) {
-        stage_put(p, lane);
+        stage_put(p, lane, n);
         {
-            float* mine = sa + 6 * lane;
-            *reinterpret_cast<f2*>(mine) = f2{b0, b1}; *reinterpret_cast<f2*>(mine + 2) = f2{b2, b3}; *reinterpret_cast<f2*>(mine + 4) = f2{b4, b5};
+            sa[lane] = b0; sa[WAVE + lane] = b1; sa[2 * WAVE + lane] = b2; sa[3 * WAVE + lane] = b3; sa[4 * WAVE + lane] = b4; sa[5 * WAVE + lane] = b5;
             __builtin_amdgcn_wave_barrier();
         }
         const int n_now = __builtin_amdgcn_readfirstlane(n);
         // the next step's photons are on their way while this step's are used
-        if (s + 1 < n_steps) {
-            p = step_photons(pos, leaf, s + 1, n_leaf, n_piv, lane, n_next, at);
-            const float* ax = aux + 6 * (size_t)at;
+        {      // (unconditional: a fetch inside a branch is waited for at its end)
+            p = step_photons(pos, leaf, s + 1 < n_steps ? s + 1 : s, n_leaf, n_piv, lane, n_next, at);
+            const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)at;
             b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
         }
+        Xyz4 c = quad_load(0);
         for (int j0 = 0; j0 < n_now; j0 += 4) {
-            const D2x4 d = quad_d2(j0, qx, qy, qz);
+            const Xyz4 c_now = c;
+            c = quad_load((j0 + 4) & (WAVE - 1));
+            const D2x4 d = quad_d2(c_now, qx, qy, qz);
+            // power and direction of the four photons: fetched with the coordinates, not inside the branch that uses them
+            const float4 pr4 = *reinterpret_cast<const float4*>(sa + j0), pg4 = *reinterpret_cast<const float4*>(sa + WAVE + j0), pb4 = *reinterpret_cast<const float4*>(sa + 2 * WAVE + j0);
+            const float4 ux4 = *reinterpret_cast<const float4*>(sa + 3 * WAVE + j0), uy4 = *reinterpret_cast<const float4*>(sa + 4 * WAVE + j0), uz4 = *reinterpret_cast<const float4*>(sa + 5 * WAVE + j0);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const int j = j0 + u;
                 const float d2 = u == 0 ? d.a.x : (u == 1 ? d.a.y : (u == 2 ? d.b.x : d.b.y));
                 bool in;
                 if (TIES) {
@@ -372,20 +393,20 @@ __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ po
                     in = d2 <= lim;
                 }
                 const unsigned long long m_in = __ballot(in);
-                if (prof_any) { c_any += m_in ? 1 : 0; c_pairs += __builtin_popcountll(m_in); }
                 if (m_in) {
-                    const f2 a01 = *reinterpret_cast<const f2*>(sa + 6 * j), a23 = *reinterpret_cast<const f2*>(sa + 6 * j + 2), a45 = *reinterpret_cast<const f2*>(sa + 6 * j + 4);
                     if (in) {
-                        const float sc = photon_term(tc, d2, nx, ny, nz, a23.y, a45.x, a45.y);
-                        s0 += (double)(a01.x * sc);          // main.cpp:286 without the hit colour, which the caller multiplies in
-                        s1 += (double)(a01.y * sc);
-                        s2 += (double)(a23.x * sc);
+                        const float pr = u == 0 ? pr4.x : (u == 1 ? pr4.y : (u == 2 ? pr4.z : pr4.w)), pg = u == 0 ? pg4.x : (u == 1 ? pg4.y : (u == 2 ? pg4.z : pg4.w));
+                        const float pb = u == 0 ? pb4.x : (u == 1 ? pb4.y : (u == 2 ? pb4.z : pb4.w)), ux = u == 0 ? ux4.x : (u == 1 ? ux4.y : (u == 2 ? ux4.z : ux4.w));
+                        const float uy = u == 0 ? uy4.x : (u == 1 ? uy4.y : (u == 2 ? uy4.z : uy4.w)), uz = u == 0 ? uz4.x : (u == 1 ? uz4.y : (u == 2 ? uz4.z : uz4.w));
+                        const float sc = photon_term(tc, d2, nx, ny, nz, ux, uy, uz);
+                        s0 += (double)(pr * sc);             // main.cpp:286 without the hit colour, which the caller multiplies in
+                        s1 += (double)(pg * sc);
+                        s2 += (double)(pb * sc);
                     }
                 }
             }
         }
     }
-    if (prof_any) { prof_any[0] += c_any; prof_any[1] += c_pairs; }
     return Sum3{s0, s1, s2};
 }
 
@@ -562,11 +583,9 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             n_leaf = select_leaves(pm.leaf_box, g_T.leaf, g_T.leaf, qx, qy, qz, 0.f, some ? t_k : -1.f, n_leaf, &n_out);      // the final balls are smaller than the bounds
             // (photons at exactly the k-th distance: if some request must leave one of them out, the pass counts them as it goes)
             if (__ballot(some && equal != want_eq))
-                sum = pass_sum<true>(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv,
-                                     ta.prof ? &pr[TP_SUM_ANY] : nullptr);
+                sum = pass_sum<true>(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv);
             else
-                sum = pass_sum<false>(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv,
-                                      ta.prof ? &pr[TP_SUM_ANY] : nullptr);
+                sum = pass_sum<false>(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv);
             pr[TP_N_SUM] += n_leaf + (n_piv + WAVE - 1) / WAVE;
             if (ta.prof) pr[TP_SUM] += clock64() - t_sum;
             if (some) {
