@@ -382,27 +382,42 @@ __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ po
             // power and direction of the four photons: fetched with the coordinates, not inside the branch that uses them
             const float4 pr4 = *reinterpret_cast<const float4*>(sa + j0), pg4 = *reinterpret_cast<const float4*>(sa + WAVE + j0), pb4 = *reinterpret_cast<const float4*>(sa + 2 * WAVE + j0);
             const float4 ux4 = *reinterpret_cast<const float4*>(sa + 3 * WAVE + j0), uy4 = *reinterpret_cast<const float4*>(sa + 4 * WAVE + j0), uz4 = *reinterpret_cast<const float4*>(sa + 5 * WAVE + j0);
+            if (TIES) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float d2 = u == 0 ? d.a.x : (u == 1 ? d.a.y : (u == 2 ? d.b.x : d.b.y));
-                bool in;
-                if (TIES) {
-                    in = d2 < lim;
+                for (int u = 0; u < 4; u++) {
+                    const float d2 = u == 0 ? d.a.x : (u == 1 ? d.a.y : (u == 2 ? d.b.x : d.b.y));
+                    bool in = d2 < lim;
                     if (d2 == lim) { in = eq_seen < want_eq; eq_seen++; }
-                } else {
-                    in = d2 <= lim;
-                }
-                const unsigned long long m_in = __ballot(in);
-                if (m_in) {
-                    if (in) {
-                        const float pr = u == 0 ? pr4.x : (u == 1 ? pr4.y : (u == 2 ? pr4.z : pr4.w)), pg = u == 0 ? pg4.x : (u == 1 ? pg4.y : (u == 2 ? pg4.z : pg4.w));
-                        const float pb = u == 0 ? pb4.x : (u == 1 ? pb4.y : (u == 2 ? pb4.z : pb4.w)), ux = u == 0 ? ux4.x : (u == 1 ? ux4.y : (u == 2 ? ux4.z : ux4.w));
-                        const float uy = u == 0 ? uy4.x : (u == 1 ? uy4.y : (u == 2 ? uy4.z : uy4.w)), uz = u == 0 ? uz4.x : (u == 1 ? uz4.y : (u == 2 ? uz4.z : uz4.w));
-                        const float sc = photon_term(tc, d2, nx, ny, nz, ux, uy, uz);
-                        s0 += (double)(pr * sc);             // main.cpp:286 without the hit colour, which the caller multiplies in
-                        s1 += (double)(pg * sc);
-                        s2 += (double)(pb * sc);
+                    if (__ballot(in)) {
+                        if (in) {
+                            const float pr = u == 0 ? pr4.x : (u == 1 ? pr4.y : (u == 2 ? pr4.z : pr4.w)), pg = u == 0 ? pg4.x : (u == 1 ? pg4.y : (u == 2 ? pg4.z : pg4.w));
+                            const float pb = u == 0 ? pb4.x : (u == 1 ? pb4.y : (u == 2 ? pb4.z : pb4.w)), ux = u == 0 ? ux4.x : (u == 1 ? ux4.y : (u == 2 ? ux4.z : ux4.w));
+                            const float uy = u == 0 ? uy4.x : (u == 1 ? uy4.y : (u == 2 ? uy4.z : uy4.w)), uz = u == 0 ? uz4.x : (u == 1 ? uz4.y : (u == 2 ? uz4.z : uz4.w));
+                            const float sc = photon_term(tc, d2, nx, ny, nz, ux, uy, uz);
+                            s0 += (double)(pr * sc);             // main.cpp:286 without the hit colour, which the caller multiplies in
+                            s1 += (double)(pg * sc);
+                            s2 += (double)(pb * sc);
+                        }
                     }
+                }
+            } else {
+                // Four photons at a time without a branch per photon: a photon outside the lane's ball contributes a
+                // factor 0.  The four terms of a channel are added in float before they join the double sum.
+                const bool in0 = d.a.x <= lim, in1 = d.a.y <= lim, in2 = d.b.x <= lim, in3 = d.b.y <= lim;
+                if (__ballot(in0 || in1 || in2 || in3)) {
+                    const f2 c2 = {tc.c2, tc.c2}, A = {tc.A, tc.A}, B = {tc.B, tc.B};
+                    const f2 ea = c2 * d.a, eb = c2 * d.b;
+                    const f2 wa = A + B * f2{__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)}, wb = A + B * f2{__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)};
+                    const f2 n_x = {nx, nx}, n_y = {ny, ny}, n_z = {nz, nz};
+                    const f2 ca = n_x * f2{ux4.x, ux4.y} + n_y * f2{uy4.x, uy4.y} + n_z * f2{uz4.x, uz4.y};
+                    const f2 cb = n_x * f2{ux4.z, ux4.w} + n_y * f2{uy4.z, uy4.w} + n_z * f2{uz4.z, uz4.w};
+                    const float sc0 = in0 ? fabsf(ca.x) * wa.x : 0.f, sc1 = in1 ? fabsf(ca.y) * wa.y : 0.f;
+                    const float sc2 = in2 ? fabsf(cb.x) * wb.x : 0.f, sc3 = in3 ? fabsf(cb.y) * wb.y : 0.f;
+                    const f2 sa = {sc0, sc1}, sb = {sc2, sc3};
+                    const f2 r = f2{pr4.x, pr4.y} * sa + f2{pr4.z, pr4.w} * sb, g = f2{pg4.x, pg4.y} * sa + f2{pg4.z, pg4.w} * sb, b = f2{pb4.x, pb4.y} * sa + f2{pb4.z, pb4.w} * sb;
+                    s0 += (double)(r.x + r.y);                   // main.cpp:286 without the hit colour, which the caller multiplies in
+                    s1 += (double)(g.x + g.y);
+                    s2 += (double)(b.x + b.y);
                 }
             }
         }

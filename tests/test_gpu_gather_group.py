@@ -38,8 +38,9 @@ def _compare(ctx, p, pos, nrm, what):
     want, _ = ctx.knn_estimate(p, pos, nrm, col)
     got = ctx.knn_estimate_grouped(p, pos, nrm, col)
     err = np.abs(got - want).max(axis=1)
-    # a request whose k-th and (k+1)-th distances are equal floats may keep the other photon
-    assert (err < 1e-9).mean() >= 0.999, (what, (err < 1e-9).mean())
+    # a request whose k-th and (k+1)-th distances are equal floats may keep the other photon; otherwise the two forms
+    # add the same float terms, the grouped one four at a time in float before its double sum: float rounding apart
+    assert (err < 1e-7).mean() >= 0.999, (what, (err < 1e-7).mean())
     assert err.max() < 2e-3, (what, err.max())
     assert want.max() > 0.05      # the comparison is not about zeros
 
@@ -70,7 +71,7 @@ def test_sparse_and_empty_maps(gpu_ctx, water_photons):
     want, cnt = gpu_ctx.knn_estimate(p, pos, nrm, col)
     got = gpu_ctx.knn_estimate_grouped(p, pos, nrm, col)
     assert cnt.max() < 1000 and cnt.max() > 0
-    assert np.abs(got - want).max() < 1e-9
+    assert np.abs(got - want).max() < 1e-7
     gpu_ctx.photons_upload(water_photons[:0])
     assert np.array_equal(gpu_ctx.knn_estimate_grouped(p, pos, nrm, col), np.zeros_like(pos))
 

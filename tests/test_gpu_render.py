@@ -211,10 +211,12 @@ def test_row_bands_and_interleave_compose_the_frame(gpu_ctx):
     full, full8, _ = gpu_ctx.render(cam, rt.default_params(width=w, height=h))
     top, _, _ = gpu_ctx.render(cam, rt.default_params(width=w, height=h), rows=(0, 20))
     bot, _, _ = gpu_ctx.render(cam, rt.default_params(width=w, height=h), rows=(20, 48))
-    assert np.abs(np.concatenate([top, bot]) - full).max() < 1e-12
+    # (another split of the rows groups the gather requests differently; a group adds four photons' terms in float
+    # before they join its double sum, so the frames agree to float rounding of a term, not to the last bit)
+    assert np.abs(np.concatenate([top, bot]) - full).max() < 5e-7
     parts = [gpu_ctx.render(cam, rt.default_params(width=w, height=h, band_rows=8, n_parts=3, part=r))[0] for r in range(3)]
     stacked = np.stack([p.reshape(h // 24, 8, w, 3) for p in parts], axis=1).reshape(h, w, 3)
-    assert np.abs(stacked - full).max() < 1e-12
+    assert np.abs(stacked - full).max() < 5e-7
 
 
 def test_render_f32_instantiation(gpu_ctx):
@@ -483,7 +485,7 @@ def test_full_size_photon_map_frame(gpu_ctx, monkeypatch):
     assert st_q.gather_single == st_q.gather_queries == st.gather_queries
     err = np.abs(rgb - rgb_q).max(axis=-1)
     # (a request whose k-th and (k+1)-th distances are equal floats may keep the other photon)
-    assert (err < 1e-9).mean() >= 0.999 and err.max() < 2e-3 and (bgr != bgr_q).mean() < 1e-3, ((err < 1e-9).mean(), err.max())
+    assert (err < 1e-7).mean() >= 0.999 and err.max() < 2e-3 and (bgr != bgr_q).mean() < 1e-3, ((err < 1e-7).mean(), err.max())
     ph = gpu_ctx.photon_map_get(0)
     assert ph.shape == (n_surface, 9)
     orc.photons_set(np.c_[ph, np.zeros(len(ph))])
