@@ -1403,21 +1403,23 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     if (prof && (rc = ctx->st_aux.reserve(rtg::TP_SLOTS * 8))) return rc;
     if (prof) HIP_TRY(hipMemsetAsync(ctx->st_aux.p, 0, rtg::TP_SLOTS * 8, ctx->stream));
     rtg::GatherParams gpt = gp;
-    if (const char* e = getenv("RT_GATHER_OPT_RANGE")) gpt.opt_range = (float)atof(e);      // tuning aid
+    if (const char* e = getenv("RT_GATHER_OPT_RANGE")) gpt.opt_range = (float)atof(e);      // tuning aids
+    if (const char* e = getenv("RT_GATHER_MIN_LANES")) gpt.min_lanes = atoi(e);
     rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
                      prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
-    hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc);
+    hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc);
     HIP_TRY(hipGetLastError());
     if (prof) {
         unsigned long long v[rtg::TP_SLOTS];
         HIP_TRY(hipMemcpyAsync(v, ctx->st_aux.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         const double nr = (double)std::max<unsigned long long>(1, v[rtg::TP_ROUNDS]);
-        fprintf(stderr, "group gather (k=%d): %llu windows, %llu rounds, %.1f requests and %.1f steps of 64 photons per round (hist %.1f, crit %.1f, sum %.1f steps; "
-                        "sum: %.0f photons in some ball, %.0f (request, photon) pairs); cycles per round: kth %.0f, walk %.0f, hist %.0f, crit %.0f, rank %.0f, sum %.0f\n",
+        fprintf(stderr, "group gather (k=%d): %llu windows, %llu rounds, %.1f requests and %.1f steps of 64 photons per round (hist %.1f, crit %.1f, sum %.1f steps); "
+                        "cycles per round: kth %.0f, walk %.0f, hist %.0f, crit %.0f, rank %.0f, sum %.0f; requests handed on: %llu other materials, %llu in small rounds, "
+                        "%llu box too large, %llu range too low, %llu range too high or crowded bin, %llu left after the last round; busy cycles per wave: mean %.0f, longest %llu\n",
                 gp.k, v[rtg::TP_WINDOWS], v[rtg::TP_ROUNDS], v[rtg::TP_LANES] / nr, v[rtg::TP_STEPS] / nr, v[rtg::TP_N_HIST] / nr, v[rtg::TP_N_CRIT] / nr, v[rtg::TP_N_SUM] / nr,
-                v[rtg::TP_SUM_ANY] / nr, v[rtg::TP_SUM_PAIRS] / nr, v[rtg::TP_KTH] / nr, v[rtg::TP_WALK] / nr, v[rtg::TP_HIST] / nr, v[rtg::TP_CRIT] / nr, v[rtg::TP_RANK] / nr,
-                v[rtg::TP_SUM] / nr);
+                v[rtg::TP_KTH] / nr, v[rtg::TP_WALK] / nr, v[rtg::TP_HIST] / nr, v[rtg::TP_CRIT] / nr, v[rtg::TP_RANK] / nr, v[rtg::TP_SUM] / nr, v[rtg::TP_R_FLAGS],
+                v[rtg::TP_R_FEW], v[rtg::TP_R_WALK], v[rtg::TP_R_SHORT], v[rtg::TP_R_CROWD], v[rtg::TP_R_LEFT], v[rtg::TP_BUSY] / (ctx->num_cus * 8.0), v[rtg::TP_BUSY_MAX]);
     }
     hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, (const uint32_t*)d_redo,
                        (const unsigned long long*)n_redo, next_gather, gp, d_acc);

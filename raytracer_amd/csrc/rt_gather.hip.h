@@ -61,17 +61,20 @@ enum ProfSlot { P_DESCENT, P_SCAN0, P_SELECT, P_N_SELECT, P_ROUNDS, P_N_ROUNDS, 
 // Per-wave working set in LDS.  The gather kernels run one wave per block, so one file-scope
 // instance serves; helper functions that are not inlined address it directly.
 struct WaveLds {
-    float key[CAP];
-    uint32_t idx[CAP];
+    float key[CAP];              // squared distances of the candidates
     uint32_t hist[256];
-    int f_lo[FRONT], f_hi[FRONT];   // frontier of pending subtrees: range and squared plane distance
-    float f_d2[FRONT];
     int c_lo[WAVE], c_n[WAVE];      // steps of the current linear scan: first photon, count (<= 64)
     int s_lo[STACK], s_hi[STACK];   // stack of the serial walk
     float s_d2[STACK];
+    // (everything above is free between two searches: the group form lays its per-lane tables over it)
+    int f_lo[FRONT], f_hi[FRONT];   // frontier of pending subtrees: range and squared plane distance
+    float f_d2[FRONT];
     unsigned long long prof[P_SLOTS];
 };
 __shared__ WaveLds g_L;
+// Tree positions of the candidates, beside g_L.key.  Only code that needs to know WHICH photons are the nearest
+// touches it (the helpers' IDS = true forms); a kernel that asks for the k-th distance alone does not pay its 8 KB.
+__shared__ uint32_t g_idx[CAP];
 
 struct Prof {
     unsigned long long* out;     // null: no accounting
@@ -83,7 +86,7 @@ struct Prof {
 
 // candidate-set state carried through the helpers by value
 struct Cand {
-    int count;       // entries in g_L.key / g_L.idx
+    int count;       // entries in g_L.key / g_idx
     float bound;     // candidates need d2 < bound
     int tight;       // the keys reach up to the bound (a select or a neighbour's hint set it): the
                      // select may bin over [0, bound] without looking for the largest key first
@@ -161,6 +164,7 @@ __device__ uint32_t radix_threshold(int count, int k, int& want)
 // leaves only a handful of entries in the bin that holds the k-th smallest; those are ranked
 // directly.  (Bins are monotonic in the key, so every entry of a lower bin is smaller.)  Crowded
 // bins -- many equal keys -- fall back to the radix passes.  Returns the k-th key.
+template <bool IDS>
 __device__ __attribute__((noinline)) Cand select_k(int count, int k, float key_limit)
 {
     WaveLds& L = g_L;
@@ -241,7 +245,7 @@ __device__ __attribute__((noinline)) Cand select_k(int count, int k, float key_l
         for (int u = 0; u < UNR; u++) {
             int j = base + u * WAVE + lane;
             ku[u] = j < count ? __float_as_uint(L.key[j]) : 0xFFFFFFFFu;   // larger than any key: never kept
-            id[u] = j < count ? L.idx[j] : 0u;
+            id[u] = IDS && j < count ? g_idx[j] : 0u;
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -254,7 +258,7 @@ __device__ __attribute__((noinline)) Cand select_k(int count, int k, float key_l
             if (keep) {
                 int p = out + (int)prefix_rank(mk);
                 L.key[p] = __uint_as_float(ku[u]);
-                L.idx[p] = id[u];
+                if (IDS) g_idx[p] = id[u];
             }
             out += __builtin_popcountll(mk);
             eq_taken += __builtin_popcountll(meq);
@@ -264,6 +268,7 @@ __device__ __attribute__((noinline)) Cand select_k(int count, int k, float key_l
     return Cand{out, __uint_as_float(T), 1};
 }
 
+template <bool IDS>
 __device__ __forceinline__ void append(int& count, bool take, float d2, uint32_t id)
 {
     WaveLds& L = g_L;
@@ -271,13 +276,14 @@ __device__ __forceinline__ void append(int& count, bool take, float d2, uint32_t
     if (take) {
         int p = count + (int)prefix_rank(m);
         L.key[p] = d2;
-        L.idx[p] = id;
+        if (IDS) g_idx[p] = id;
     }
     count += __builtin_popcountll(m);
 }
 
 // Make room for `need` more candidates (need <= GROUP * WAVE): if they might not fit, keep the k
 // nearest and tighten the bound.  count > k holds whenever this triggers (k <= MAX_K).
+template <bool IDS>
 __device__ __forceinline__ void make_room(Cand& c, int k, int need, Prof pf)
 {
     // also once the set has grown to twice k (small k): an early, cheap select tightens the bound
@@ -286,7 +292,7 @@ __device__ __forceinline__ void make_room(Cand& c, int k, int need, Prof pf)
     if (c.count > CAP - need || c.count > early) {
         __builtin_amdgcn_wave_barrier();
         unsigned long long t = pf.now();
-        c = select_k(c.count, k, c.tight ? c.bound : 0.f);
+        c = select_k<IDS>(c.count, k, c.tight ? c.bound : 0.f);
         pf.add(P_SELECT, pf.now() - t); pf.add(P_N_SELECT, 1);
     }
 }
@@ -294,6 +300,7 @@ __device__ __forceinline__ void make_room(Cand& c, int k, int need, Prof pf)
 // Linear scan of the n_steps (<= 64) steps listed in L.c_lo / L.c_n.  The loads of FLIGHT steps are
 // issued together (one memory round trip per FLIGHT x 64 photons); room in the candidate buffer is
 // checked before every GROUP steps.
+template <bool IDS>
 __device__ __attribute__((noinline)) Cand scan_steps(PhotonMapView pm, float qx, float qy, float qz, int n_steps, int k, Cand c, Prof pf)
 {
     const WaveLds& L = g_L;
@@ -316,7 +323,7 @@ __device__ __attribute__((noinline)) Cand scan_steps(PhotonMapView pm, float qx,
 #pragma unroll
         for (int v = 0; v < FLIGHT; v += GROUP) {
             if (g + v < n_steps) {
-                make_room(c, k, GROUP * WAVE, pf);
+                make_room<IDS>(c, k, GROUP * WAVE, pf);
 #pragma unroll
                 for (int w = 0; w < GROUP; w++) {
                     const int u = v + w;
@@ -325,7 +332,7 @@ __device__ __attribute__((noinline)) Cand scan_steps(PhotonMapView pm, float qx,
                         float dx = qx - px[u], dy = qy - py[u], dz = qz - pz[u];
                         d2 = dx * dx + dy * dy + dz * dz;
                     }
-                    append(c.count, valid[u] && d2 < c.bound, d2, (uint32_t)id[u]);
+                    append<IDS>(c.count, valid[u] && d2 < c.bound, d2, (uint32_t)id[u]);
                 }
             }
         }
@@ -334,6 +341,7 @@ __device__ __attribute__((noinline)) Cand scan_steps(PhotonMapView pm, float qx,
 }
 
 // Linear scan of one contiguous range (a whole subtree), any length.
+template <bool IDS>
 __device__ __forceinline__ Cand scan_range(const PhotonMapView& pm, float qx, float qy, float qz, int lo, int hi, int k, Cand c, Prof pf)
 {
     WaveLds& L = g_L;
@@ -348,13 +356,14 @@ __device__ __forceinline__ Cand scan_range(const PhotonMapView& pm, float qx, fl
             L.c_n[lane] = hi - first < WAVE ? hi - first : WAVE;
         }
         __builtin_amdgcn_wave_barrier();
-        c = scan_steps(pm, qx, qy, qz, steps, k, c, pf);
+        c = scan_steps<IDS>(pm, qx, qy, qz, steps, k, c, pf);
         lo += steps * WAVE;
     }
     return c;
 }
 
 // Serial depth-first walk of one subtree (all lanes in step); used when the frontier is full.
+template <bool IDS>
 __device__ __attribute__((noinline)) Cand walk_serial(PhotonMapView pm, float qx, float qy, float qz, int lo, int hi, int k, Cand c, Prof pf)
 {
     WaveLds& L = g_L;
@@ -377,8 +386,8 @@ __device__ __attribute__((noinline)) Cand walk_serial(PhotonMapView pm, float qx
             float px = pv.x, py = pv.y, pz = pv.z;
             float dx = qx - px, dy = qy - py, dz = qz - pz;
             float d2 = dx * dx + dy * dy + dz * dz;
-            make_room(c, k, WAVE, pf);
-            append(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119)
+            make_room<IDS>(c, k, WAVE, pf);
+            append<IDS>(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119)
             float split = ax == 0 ? px : (ax == 1 ? py : pz);
             float delta = (ax == 0 ? qx : (ax == 1 ? qy : qz)) - split;
             int nlo, nhi, flo, fhi;
@@ -391,16 +400,17 @@ __device__ __attribute__((noinline)) Cand walk_serial(PhotonMapView pm, float qx
             }
             lo = nlo; hi = nhi;
         }
-        c = scan_range(pm, qx, qy, qz, lo, hi, k, c, pf);
+        c = scan_range<IDS>(pm, qx, qy, qz, lo, hi, k, c, pf);
         __builtin_amdgcn_wave_barrier();
     }
     return c;
 }
 
 // k nearest photons within sqrt(r2) of one query held identically by all lanes.  Returns the
-// number of photons found; g_L.key / g_L.idx[0..count) is the set.
+// number of photons found; g_L.key / g_idx[0..count) is the set (IDS = false: the distances only).
 // `hint` > 0: a bound known to contain at least k photons (from a neighbouring query, see
 // knn_collect); then steps 1's scan is skipped and the whole tree goes through the frontier.
+template <bool IDS>
 __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, float hint, int front_cap,
                                                  Prof pf)
 {
@@ -428,7 +438,7 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
         float px = pv.x, py = pv.y, pz = pv.z;
         float dx = qx - px, dy = qy - py, dz = qz - pz;
         float d2 = dx * dx + dy * dy + dz * dz;
-        append(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119); < 32 of these
+        append<IDS>(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119); < 32 of these
         float split = ax == 0 ? px : (ax == 1 ? py : pz);
         float delta = (ax == 0 ? qx : (ax == 1 ? qy : qz)) - split;
         int nlo, nhi, flo, fhi;
@@ -443,12 +453,12 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
     }
     unsigned long long t1 = pf.now();
     pf.add(P_DESCENT, t1 - t0);
-    c = scan_range(pm, qx, qy, qz, lo, hi, k, c, pf);
+    c = scan_range<IDS>(pm, qx, qy, qz, lo, hi, k, c, pf);
     t0 = pf.now();
     pf.add(P_SCAN0, t0 - t1);
     if (c.count > k) {
         __builtin_amdgcn_wave_barrier();
-        c = select_k(c.count, k, c.tight ? c.bound : 0.f);
+        c = select_k<IDS>(c.count, k, c.tight ? c.bound : 0.f);
         t1 = pf.now();
         pf.add(P_SELECT, t1 - t0); pf.add(P_N_SELECT, 1);
     }
@@ -493,8 +503,8 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
             else { nlo = mid + 1; nhi = rhi; flo = rlo; fhi = mid; }
             dd = delta * delta;
         }
-        make_room(c, k, WAVE, pf);
-        append(c.count, is_inner && d2 < c.bound, d2, (uint32_t)mid);
+        make_room<IDS>(c, k, WAVE, pf);
+        append<IDS>(c.count, is_inner && d2 < c.bound, d2, (uint32_t)mid);
         const bool push_far = is_inner && fhi > flo && dd <= c.bound;
         const bool push_near = is_inner && nhi > nlo;
         const unsigned long long m_far = __ballot(push_far), m_near = __ballot(push_near), m_leaf = __ballot(is_leaf);
@@ -504,7 +514,7 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
         if (n_pend > 0 && (n_pend + n_leaf > WAVE || !fits)) {
             // (the serial walk of a full frontier uses the leaf list as its own scratch)
             unsigned long long ts = pf.now();
-            c = scan_steps(pm, qx, qy, qz, n_pend, k, c, pf);
+            c = scan_steps<IDS>(pm, qx, qy, qz, n_pend, k, c, pf);
             pf.add(P_LEAVES, pf.now() - ts); pf.add(P_N_LEAVES, n_pend);
             n_pend = 0;
             __builtin_amdgcn_wave_barrier();
@@ -528,7 +538,7 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
         if (!fits) {
             // frontier full: walk this round's children serially instead, lane by lane
             if (n_pend > 0) {
-                c = scan_steps(pm, qx, qy, qz, n_pend, k, c, pf);
+                c = scan_steps<IDS>(pm, qx, qy, qz, n_pend, k, c, pf);
                 pf.add(P_N_LEAVES, n_pend);
                 n_pend = 0;
                 __builtin_amdgcn_wave_barrier();
@@ -539,21 +549,21 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
                 todo &= todo - 1;
                 int a_lo = __shfl(nlo, src), a_hi = __shfl(nhi, src), b_lo = __shfl(flo, src), b_hi = __shfl(fhi, src);
                 float b_dd = __shfl(dd, src);
-                if ((m_near >> src) & 1ull) c = walk_serial(pm, qx, qy, qz, a_lo, a_hi, k, c, pf);
-                if (((m_far >> src) & 1ull) && !(b_dd > c.bound)) c = walk_serial(pm, qx, qy, qz, b_lo, b_hi, k, c, pf);
+                if ((m_near >> src) & 1ull) c = walk_serial<IDS>(pm, qx, qy, qz, a_lo, a_hi, k, c, pf);
+                if (((m_far >> src) & 1ull) && !(b_dd > c.bound)) c = walk_serial<IDS>(pm, qx, qy, qz, b_lo, b_hi, k, c, pf);
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (n_pend > 0) {
         t0 = pf.now();
-        c = scan_steps(pm, qx, qy, qz, n_pend, k, c, pf);
+        c = scan_steps<IDS>(pm, qx, qy, qz, n_pend, k, c, pf);
         pf.add(P_LEAVES, pf.now() - t0); pf.add(P_N_LEAVES, n_pend);
     }
     if (c.count > k) {
         __builtin_amdgcn_wave_barrier();
         t0 = pf.now();
-        c = select_k(c.count, k, c.tight ? c.bound : 0.f);
+        c = select_k<IDS>(c.count, k, c.tight ? c.bound : 0.f);
         pf.add(P_SELECT, pf.now() - t0); pf.add(P_N_SELECT, 1);
     }
     return c;
@@ -569,6 +579,7 @@ struct Neighbour {
     float radius;     // k-th nearest distance of the previous query; < 0: none
 };
 
+template <bool IDS = true>
 __device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, int front_cap, Prof pf,
                                            Neighbour* nb = nullptr)
 {
@@ -578,11 +589,11 @@ __device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, fl
         float reach = nb->radius + sqrtf(dx * dx + dy * dy + dz * dz);
         hint = reach * reach * 1.001f + 1e-12f;       // slack for the rounding of the distances
     }
-    Cand c = knn_collect_from(pm, qx, qy, qz, k, r2, hint, front_cap, pf);
+    Cand c = knn_collect_from<IDS>(pm, qx, qy, qz, k, r2, hint, front_cap, pf);
     if (hint > 0.f && hint < r2 && c.count < k) {
         // cannot happen in exact arithmetic; never return a short set because of a hint
         __builtin_amdgcn_wave_barrier();
-        c = knn_collect_from(pm, qx, qy, qz, k, r2, 0.f, front_cap, pf);
+        c = knn_collect_from<IDS>(pm, qx, qy, qz, k, r2, 0.f, front_cap, pf);
     }
     if (nb) {
         nb->x = qx; nb->y = qy; nb->z = qz;
@@ -600,6 +611,7 @@ struct GatherParams {
     double photon_num;   // PHOTONMUM as a double: the volume normaliser divides in floating point (main.cpp:332)
     uint32_t seed;       // of the march's step lengths (main.cpp:374)
     float opt_range = 0.3f;   // group form: widest relative range around the centre's k-th distance searched for a neighbour's (>= 1: the rigorous range)
+    int min_lanes = 0;        // group form: fewest requests worth a round of their own (0: chosen from k)
 };
 
 // reduce a double over the wave (all lanes get lane 0's total after the final shuffle)
@@ -665,7 +677,7 @@ __device__ void estimate_raw(const PhotonMapView& pm, int count, const double* n
             valid[u] = j < count;
             const int jj = valid[u] ? j : count - 1;      // unconditional fetches (clamped): all in flight together
             dsq[u] = L.key[jj];
-            const float* src = pm.aux + 6 * (size_t)L.idx[jj];
+            const float* src = pm.aux + 6 * (size_t)g_idx[jj];
 #pragma unroll
             for (int c = 0; c < 6; c++) a[u][c] = src[c];
         }
@@ -716,7 +728,7 @@ __device__ void volume_step(const PhotonMapView& vm, int count, const float* hit
     uint32_t far_idx = 0;
     for (int j = lane; j < count; j += WAVE) {
         float key = L.key[j];
-        uint32_t id = L.idx[j];
+        uint32_t id = g_idx[j];
         const float* a = vm.aux + 6 * (size_t)id;
         p0 += (col[0] * (double)a[0]) * 0.2;      // main.cpp:329, 368
         p1 += (col[1] * (double)a[1]) * 0.2;
@@ -851,7 +863,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         }
         if (rgb_out && lane < 3) rgb_out[3 * q + lane] = lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2]);
         if (idx_out) {   // the set itself, in the caller's numbering, -1 padded to k
-            for (int j = lane; j < gp.k; j += WAVE) idx_out[(size_t)q * gp.k + j] = j < count ? pm.order[L.idx[j]] : -1;
+            for (int j = lane; j < gp.k; j += WAVE) idx_out[(size_t)q * gp.k + j] = j < count ? pm.order[g_idx[j]] : -1;
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -24,12 +24,16 @@
 
 namespace rtg {
 
-constexpr int T_BINS = 64;        // histogram bins per request
-constexpr int T_CRIT = 48;        // distances of the critical bin kept per request
+constexpr int T_BINS = 80;        // histogram bins per request
+constexpr int T_CRIT = 40;        // distances of the critical bin kept per request
 constexpr int T_LEAVES = 320;     // leaves a group's box may touch
 constexpr int T_PIVOTS = 512;     // inner-node pivots inside a group's box
-static_assert(T_BINS * WAVE * 4 <= CAP * 8 && T_CRIT * WAVE * 4 <= CAP * 8, "the per-lane tables overlay the candidate buffer");
-static_assert(offsetof(WaveLds, idx) == offsetof(WaveLds, key) + CAP * sizeof(float), "key and idx are one block");
+// The per-lane tables lie over what the search for the centre's k-th distance leaves free: the candidates' distances
+// and the arrays after them, up to the frontier.  (The histogram holds two 16-bit counts per word: a group lists at
+// most T_LEAVES * 64 + T_PIVOTS photons.)
+constexpr size_t T_TABLE_BYTES = offsetof(WaveLds, f_lo) - offsetof(WaveLds, key);
+static_assert(offsetof(WaveLds, key) == 0 && T_BINS * WAVE * 2 <= T_TABLE_BYTES && T_CRIT * WAVE * 4 <= T_TABLE_BYTES, "the per-lane tables fit");
+static_assert(T_LEAVES * 64 + T_PIVOTS < 65536 && T_BINS % 2 == 0, "histogram counts fit 16 bits; bins 2i and 2i + 1 share a word");
 
 struct TileLds {
     uint32_t leaf[T_LEAVES];      // first photon << 7 | photons (<= 64): the leaves some request's ball touches
@@ -74,7 +78,8 @@ struct TileArgs {
     int all_redo;                    // nonzero: hand every request to the per-query kernel (comparison runs)
     unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
 };
-enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_N_HIST, TP_N_CRIT, TP_N_SUM, TP_SUM_ANY, TP_SUM_PAIRS, TP_SLOTS };
+enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_N_HIST, TP_N_CRIT, TP_N_SUM,
+                TP_R_FLAGS, TP_R_FEW, TP_R_WALK, TP_R_SHORT, TP_R_CROWD, TP_R_LEFT, TP_BUSY, TP_BUSY_MAX, TP_SLOTS };      // TP_R_*: requests handed on, by reason
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // two photons per packed instruction
 
@@ -128,7 +133,7 @@ __device__ __forceinline__ float4 step_photons(const float4* __restrict__ pos, c
 __device__ __attribute__((noinline)) float kth_distance(PhotonMapView pm, float cx, float cy, float cz, int k, float r2, int front_cap)
 {
     Neighbour nb{0.f, 0.f, 0.f, -1.f};
-    knn_collect(pm, cx, cy, cz, k, r2, front_cap, Prof{nullptr}, &nb);
+    knn_collect<false>(pm, cx, cy, cz, k, r2, front_cap, Prof{nullptr}, &nb);      // (the distances alone: no photon ids kept)
     return nb.radius;
 }
 
@@ -223,6 +228,8 @@ __device__ __forceinline__ D2x4 quad_d2(const Xyz4& c, float qx, float qy, float
 __device__ __forceinline__ float shell_scale(float bound, float lower) { return ((float)(T_BINS - 2) * 0.999999f) / (bound - lower); }
 __device__ __forceinline__ f2 shell_pos(f2 d2, float lower, float scale) { return (d2 - f2{lower, lower}) * f2{scale, scale} + f2{1.f, 1.f}; }
 __device__ __forceinline__ int shell_bin_of(float pos) { return (int)__builtin_amdgcn_fmed3f(pos, 0.f, (float)(T_BINS - 1)); }
+// The histogram of a lane: word (b >> 1) * 64 + lane holds the count of bin b in its low half (b even) or its high half.
+__device__ __forceinline__ void hist_add(uint32_t* mine, int bin) { atomicAdd(mine + (bin >> 1) * WAVE, (bin & 1) * 0xFFFFu + 1u); }
 
 // Copy to `dst` the leaves of `src` that some lane has to look at photon by photon: those with a photon
 // possibly at a squared distance in [lo_lim, hi_lim] from the lane's point (hi_lim < 0: the lane takes no
@@ -260,16 +267,16 @@ __device__ __attribute__((noinline)) int select_leaves(const float* __restrict__
     return out;
 }
 
-__device__ __forceinline__ uint32_t* lane_tables() { return reinterpret_cast<uint32_t*>(g_L.key); }   // [row][lane] over the candidate buffer
+__device__ __forceinline__ uint32_t* lane_tables() { return reinterpret_cast<uint32_t*>(g_L.key); }   // [row][lane] over the candidates' distances
 
-// 3a: cell[bin][lane] = photons of the list whose squared distance to the lane's point falls into the bin
+// 3a: the lane's histogram (see hist_add) of the squared distances from its point to the photons of the list
 __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float lower, float scale,
                                                     int n_leaf, int n_piv)
 {
     uint32_t* const cell = lane_tables();
     const int lane = lane_id();
 #pragma unroll 8
-    for (int b = 0; b < T_BINS; b++) cell[b * WAVE + lane] = 0u;
+    for (int b = 0; b < T_BINS / 2; b++) cell[b * WAVE + lane] = 0u;
     __builtin_amdgcn_wave_barrier();
     n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);      // (the same in every lane: let the compiler know)
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
@@ -281,17 +288,22 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
         const int n_now = __builtin_amdgcn_readfirstlane(n);
         // the next step's photons are on their way while this step's are used
         p = step_photons(pos, leaf, s + 1 < n_steps ? s + 1 : s, n_leaf, n_piv, lane, n_next, at);      // (unconditional: a fetch inside a branch is waited for at its end)
-        // (the coordinates of the next four photons are read from LDS while the current four are binned)
-        Xyz4 c = quad_load(0);
-        for (int j0 = 0; j0 < n_now; j0 += 4) {
-            const Xyz4 c_now = c;
-            c = quad_load((j0 + 4) & (WAVE - 1));
-            const D2x4 d = quad_d2(c_now, qx, qy, qz);
+        // (the coordinates of the next four photons are read from LDS while the current four are binned; two register
+        // sets take turns, so nothing is copied)
+        auto bin4 = [&](const Xyz4& c) {
+            const D2x4 d = quad_d2(c, qx, qy, qz);
             const f2 at_a = shell_pos(d.a, lower, scale), at_b = shell_pos(d.b, lower, scale);
-            atomicAdd(mine + shell_bin_of(at_a.x) * WAVE, 1u);
-            atomicAdd(mine + shell_bin_of(at_a.y) * WAVE, 1u);
-            atomicAdd(mine + shell_bin_of(at_b.x) * WAVE, 1u);
-            atomicAdd(mine + shell_bin_of(at_b.y) * WAVE, 1u);
+            hist_add(mine, shell_bin_of(at_a.x));
+            hist_add(mine, shell_bin_of(at_a.y));
+            hist_add(mine, shell_bin_of(at_b.x));
+            hist_add(mine, shell_bin_of(at_b.y));
+        };
+        Xyz4 c0 = quad_load(0), c1;
+        for (int j0 = 0; j0 < n_now; j0 += 8) {
+            c1 = quad_load(j0 + 4);
+            bin4(c0);
+            c0 = quad_load((j0 + 8) & (WAVE - 1));
+            if (j0 + 4 < n_now) bin4(c1);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -432,6 +444,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const rtq::Map map = rtq::map_units(ta.cnt, ta.shard_cap, WAVE);
     const uint32_t n_windows = map.total;
     unsigned long long pr[TP_SLOTS] = {};
+    const unsigned long long t_begin = ta.prof ? clock64() : 0ull;
 #define TILE_PROF(slot, expr) do { if (ta.prof) { const unsigned long long t_ = clock64(); expr; pr[slot] += clock64() - t_; } else { expr; } } while (0)
     while (true) {
         unsigned long long w0 = 0;
@@ -451,13 +464,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         bool redo = have && (flags != 0 || ta.all_redo || pm.n >= (1ll << 24));
         bool todo = have && !redo;
         pr[TP_WINDOWS]++;
+#define TILE_COUNT(slot, cond) do { if (ta.prof) pr[slot] += __builtin_popcountll(__ballot(cond)); } while (0)
+        TILE_COUNT(TP_R_FLAGS, redo);
         // A window mostly holds one patch of neighbouring hit points, but it may hold a few (a tile across a
         // silhouette, two producers' requests in one window): each round takes the requests close to one of
         // those still waiting; what is left after ROUNDS rounds, and rounds of only a few requests, go to the
         // per-request kernel.
-        // (a round costs about as much as 20 requests answered singly at k = 1000, as 8 at k = 100)
-        constexpr int ROUNDS = 4;
-        const int MIN_LANES = gp.k >= 400 ? 20 : 10;
+        // (measured: the frame time is flat for 12 .. 28 requests at k = 1000 and for 4 .. 8 at k = 100)
+        constexpr int ROUNDS = 6;
+        const int MIN_LANES = gp.min_lanes > 0 ? gp.min_lanes : (gp.k >= 400 ? 20 : 6);
         for (int round = 0; round < ROUNDS; round++) {
             const unsigned long long m_todo = __ballot(todo);
             if (!m_todo) break;
@@ -476,6 +491,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             // ball they are not worth a round of their own
             bool act = todo && d_c <= sqrtf(gp.r2);
             if (__builtin_popcountll(__ballot(act)) < MIN_LANES) {
+                TILE_COUNT(TP_R_FEW, act);
                 redo = redo || act;
                 todo = todo && !act;
                 continue;
@@ -504,6 +520,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             }
             if (__builtin_popcountll(__ballot(act)) < MIN_LANES) {
                 // (the centre itself is always among them, so every round retires at least one request)
+                TILE_COUNT(TP_R_FEW, act);
                 redo = redo || act;
                 todo = todo && !act;
                 continue;
@@ -516,7 +533,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             const float ghx = wave_max_f(act ? qx + rad : -big), ghy = wave_max_f(act ? qy + rad : -big), ghz = wave_max_f(act ? qz + rad : -big);
             int lists;
             TILE_PROF(TP_WALK, lists = group_walk(pm, glx, gly, glz, ghx, ghy, ghz));
-            if (lists < 0) { redo = redo || act; continue; }
+            if (lists < 0) { TILE_COUNT(TP_R_WALK, act); redo = redo || act; continue; }
             int n_leaf = lists & 0xFFFF;
             const int n_piv = lists >> 16;
             // the walk lists what touches the box around the balls; the corners of that box touch no ball
@@ -531,25 +548,32 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             const int n_hist = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, act ? lower : 3.0e38f, act ? 3.0e38f : -1.f, n_leaf, &n_inside);
             TILE_PROF(TP_HIST, pass_hist(pm.pos, g_T.part, qx, qy, qz, lower, scale, n_hist, n_piv));
             pr[TP_N_HIST] += n_hist + (n_piv + WAVE - 1) / WAVE;
-            if (act) cell[lane] += (uint32_t)n_inside;
+            if (act) cell[lane] += (uint32_t)n_inside;             // (bin 0: the low half of word 0)
             // the bin holding the lane's k-th smallest distance (or its largest, if fewer than k lie within the bound)
             uint32_t total = 0;                                   // (the last bin holds what lies beyond the bound)
 #pragma unroll 4
-            for (int b = 0; b < T_BINS - 1; b++) total += cell[b * WAVE + lane];
+            for (int b = 0; b < T_BINS / 2; b++) { const uint32_t w = cell[b * WAVE + lane]; total += (w & 0xFFFFu) + (b < T_BINS / 2 - 1 ? w >> 16 : 0u); }      // (bins 2b, 2b + 1)
             const uint32_t k_eff = total < (uint32_t)gp.k ? total : (uint32_t)gp.k;
             // a bound derived from the neighbour must contain k photons; if it somehow does not, the per-query kernel decides
+            TILE_COUNT(TP_R_SHORT, act && total < (uint32_t)gp.k && bound < gp.r2);
             if (act && total < (uint32_t)gp.k && bound < gp.r2) { redo = true; act = false; }
             int crit = -1;
             uint32_t below = 0, in_bin = 0;
             {
                 uint32_t cum = 0;
 #pragma unroll 4
-                for (int b = 0; b < T_BINS - 1; b++) {
-                    const uint32_t h = cell[b * WAVE + lane];
-                    if (crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
-                    cum += h;
+                for (int w = 0; w < T_BINS / 2; w++) {
+                    const uint32_t both = cell[w * WAVE + lane];
+#pragma unroll
+                    for (int half = 0; half < 2; half++) {
+                        const int b = 2 * w + half;
+                        const uint32_t h = half ? both >> 16 : both & 0xFFFFu;
+                        if (b < T_BINS - 1 && crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
+                        cum += h;
+                    }
                 }
             }
+            TILE_COUNT(TP_R_CROWD, act && in_bin > (uint32_t)T_CRIT);
             if (act && in_bin > (uint32_t)T_CRIT) { redo = true; act = false; }
             const bool some = act && k_eff > 0;
             const int need = (int)(k_eff - below);                 // 1-based rank of the k-th smallest inside its bin
@@ -611,6 +635,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             }
             __builtin_amdgcn_wave_barrier();
         }
+        TILE_COUNT(TP_R_LEFT, todo);
         redo = redo || todo;
         // ---- requests left to the per-query kernel
         const unsigned long long m_redo = __ballot(redo);
@@ -624,8 +649,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         __builtin_amdgcn_wave_barrier();
     }
 #undef TILE_PROF
-    if (ta.prof && lane == 0)
-        for (int i = 0; i < TP_SLOTS; i++) atomicAdd(&ta.prof[i], pr[i]);
+#undef TILE_COUNT
+    if (ta.prof && lane == 0) {
+        pr[TP_BUSY] = clock64() - t_begin;
+        for (int i = 0; i < TP_BUSY_MAX; i++) atomicAdd(&ta.prof[i], pr[i]);
+        atomicMax(&ta.prof[TP_BUSY_MAX], pr[TP_BUSY]);
+    }
 }
 
 }  // namespace rtg
