@@ -112,6 +112,8 @@ struct rt_context {
     int device = 0;
     int num_cus = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;         // the per-request gather that runs alongside the group gather
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // order between the two streams
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> chunk_ev;   // begin / end of the trace + shade launches of every row chunk of a timed frame
     // flattened scene in HBM, both instantiations
@@ -327,10 +329,21 @@ int rt_context_create(int device, rt_context** out)
             delete ctx;
             return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(se));
         }
+        // (the hand-over list is all "empty" between calls: set once here, kept so by the kernels that read it)
+        if (hipMemset((unsigned char*)at + NA_COUNTERS + NA_QUEUE, 0xFF, NA_REDO) != hipSuccess) {
+            (void)hipStreamDestroy(ctx->stream);
+            delete ctx;
+            return fail(RT_ERR_HIP, "hipMemset(scratch) on device %d failed", device);
+        }
         g_scratch_at[device] = (unsigned char*)at;
     }
     for (auto& ev : ctx->ev)
         if (hipEventCreate(&ev) != hipSuccess) { delete ctx; return fail(RT_ERR_HIP, "hipEventCreate failed"); }
+    if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        rt_context_destroy(ctx);
+        return fail(RT_ERR_HIP, "cannot create the second stream of device %d", device);
+    }
     // per-call counter block of every kernel family + the overflow latch behind it; never reallocated
     static_assert(sizeof(rtr::RenderCounters) <= rtk::LATCH_OFFSET && sizeof(rte::EmitCounters) <= rtk::LATCH_OFFSET && sizeof(rtk::TraceCounters) <= rtk::LATCH_OFFSET,
                   "the counter blocks end before the overflow latch");
@@ -347,6 +360,7 @@ void rt_context_destroy(rt_context* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
                       &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->redo, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
@@ -356,6 +370,9 @@ void rt_context_destroy(rt_context* ctx)
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->chunk_ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1278,7 +1295,9 @@ int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const
 
 namespace {
 int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
-                  unsigned long long* n_redo, unsigned long long* next_gather, const rtg::GatherParams& gp, double* d_acc, uint32_t* d_redo, bool may_profile = true);
+                  unsigned long long* n_redo, unsigned long long* next_gather, unsigned long long* windows_done, const rtg::GatherParams& gp, double* d_acc,
+                  uint32_t* d_redo, size_t redo_entries, bool may_profile = true);
+int reserve_redo(rt_context* ctx, size_t entries);
 }
 extern "C" {
 
@@ -1305,7 +1324,7 @@ int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t 
         if (i % 64 == 0) g.flags = (uint32_t)std::min<int64_t>(64, n - i) << rtg::GATHER_COUNT_SHIFT;
     }
     if ((rc = upload(ctx->gq, recs, ctx->stream))) return rc;
-    if ((rc = ctx->redo.reserve(slots * sizeof(uint32_t)))) return rc;
+    if ((rc = reserve_redo(ctx, slots))) return rc;
     if ((rc = ctx->acc.reserve((size_t)n * 3 * sizeof(double)))) return rc;
     rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
     HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rtr::RenderCounters), ctx->stream));
@@ -1319,8 +1338,8 @@ int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t 
     gp.norm = (double)(p->photon_num / 16) * 3.1415926;
     gp.photon_num = (double)p->photon_num;
     gp.seed = 12345u;
-    if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp,
-                            (double*)ctx->acc.p, (uint32_t*)ctx->redo.p)))
+    if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, ctr->tile_progress, gp,
+                            (double*)ctx->acc.p, (uint32_t*)ctx->redo.p, ctx->redo.bytes / sizeof(uint32_t))))
         return rc;
     HIP_TRY(hipMemcpyAsync(rgb, ctx->acc.p, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));    // also: `recs` and `n_slots` die at return
@@ -1384,7 +1403,8 @@ int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int6
     gp.norm = (double)(p->photon_num / 16) * 3.1415926;
     gp.photon_num = (double)p->photon_num;
     gp.seed = 12345u;
-    return launch_gather(ctx, recs, &ctr->gather, (unsigned long long)slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp, d_rgb, redo, false);
+    return launch_gather(ctx, recs, &ctr->gather, (unsigned long long)slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, ctr->tile_progress, gp, d_rgb, redo,
+                         NA_REDO / sizeof(uint32_t), false);
     });
 }
 }  // extern "C"
@@ -1394,7 +1414,8 @@ namespace {
 // The gather over a queue of request windows: the group kernel, then the per-request kernel for what it
 // left.  RT_GATHER_MODE=query hands every request to the per-request kernel (comparison runs).
 int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
-                  unsigned long long* n_redo, unsigned long long* next_gather, const rtg::GatherParams& gp, double* d_acc, uint32_t* d_redo, bool may_profile)
+                  unsigned long long* n_redo, unsigned long long* next_gather, unsigned long long* windows_done, const rtg::GatherParams& gp, double* d_acc,
+                  uint32_t* d_redo, size_t redo_entries, bool may_profile)
 {
     const char* mode = getenv("RT_GATHER_MODE");
     // RT_GATHER_PROF=1: per-phase cycle totals of the group kernel, printed to stderr (development aid)
@@ -1405,10 +1426,20 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     rtg::GatherParams gpt = gp;
     if (const char* e = getenv("RT_GATHER_OPT_RANGE")) gpt.opt_range = (float)atof(e);      // tuning aids
     if (const char* e = getenv("RT_GATHER_MIN_LANES")) gpt.min_lanes = atoi(e);
-    rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
+    rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, windows_done, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
                      prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
+    HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));      // (the queue and the counters are ready here)
     hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc);
     HIP_TRY(hipGetLastError());
+    // The per-request kernel alongside, on the second stream.  Its waves stay only once every wave of the group kernel
+    // has begun, so they never hold a place the group kernel waits for; six blocks per CU leave room for one of the
+    // group kernel's in any case.
+    HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(rtg::gather_alongside_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->side, ctx->pm[0], ctx->pm[1], recs, d_redo,
+                       (uint32_t)std::min<size_t>(redo_entries, 0xFFFFFFFFu), cnt, shard_cap, (const unsigned long long*)windows_done, (unsigned)(ctx->num_cus * 8),
+                       next_gather, gp, d_acc);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
     if (prof) {
         unsigned long long v[rtg::TP_SLOTS];
         HIP_TRY(hipMemcpyAsync(v, ctx->st_aux.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
@@ -1421,22 +1452,33 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
                 v[rtg::TP_KTH] / nr, v[rtg::TP_WALK] / nr, v[rtg::TP_HIST] / nr, v[rtg::TP_CRIT] / nr, v[rtg::TP_RANK] / nr, v[rtg::TP_SUM] / nr, v[rtg::TP_R_FLAGS],
                 v[rtg::TP_R_FEW], v[rtg::TP_R_WALK], v[rtg::TP_R_SHORT], v[rtg::TP_R_CROWD], v[rtg::TP_R_LEFT], v[rtg::TP_BUSY] / (ctx->num_cus * 8.0), v[rtg::TP_BUSY_MAX]);
     }
-    hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, (const uint32_t*)d_redo,
+    hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, d_redo,
                        (const unsigned long long*)n_redo, next_gather, gp, d_acc);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // what follows on the stream follows both
+    return RT_OK;
+}
+
+// The hand-over list for `entries` requests.  Fresh memory is set to "empty"; the kernels that read entries reset them.
+int reserve_redo(rt_context* ctx, size_t entries)
+{
+    const size_t before = ctx->redo.bytes;
+    int rc = ctx->redo.reserve(std::max<size_t>(entries, 64) * sizeof(uint32_t));
+    if (rc) return rc;
+    if (ctx->redo.bytes != before) HIP_TRY(hipMemsetAsync(ctx->redo.p, 0xFF, ctx->redo.bytes, ctx->stream));
     return RT_OK;
 }
 
 // the three traversal kernels of the render path for one (R, TRI_ONLY, MODE) choice
 template <class R, bool TRI_ONLY, int MODE, bool COUNT = false>
-int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceGeom& g, int levels, unsigned long long shard_cap,
+int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceGeom& g, int levels, unsigned long long shard_cap, unsigned long long gq_cap,
                          rtr::RenderCounters* ctr, double* d_acc)
 {
     const int rows = a.row_end - a.row_begin;
     const int cap = stack_cap(ctx);
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int wpb = g.threads / 64;
-    const dim3 grid((unsigned)rtk::tile_grid_blocks((a.width + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth));
+    const dim3 grid((unsigned)rtk::tile_grid_blocks((a.col_end - a.col_begin + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth));
     if (COUNT)
         hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE, false, COUNT>), grid, dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
                            (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
@@ -1456,7 +1498,7 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     for (int level = 1; level <= levels; level++) {
         const int last = level == levels ? 1 : 0;
         hipLaunchKernelGGL(rtr::shade_kernel, dim3(shade_blocks), dim3(rtk::BLOCK), 0, ctx->stream, sd, a, level, last, qin, (rtr::RayRec*)ctx->rays.p,
-                           (rtg::GatherRec*)ctx->gq.p, shard_cap, ctr);
+                           (rtg::GatherRec*)ctx->gq.p, shard_cap, gq_cap, ctr);
         HIP_TRY(hipGetLastError());
         if (!last) {
             hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE, COUNT>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
@@ -1468,29 +1510,48 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     return RT_OK;
 }
 
+// Capacities of the queues of the render path, per shard (32 shards each; multiples of 64: queues are filled in
+// windows of 64 slots).  hits / rays hold one recursion level at a time; the gather queue takes requests from
+// every level.
+struct QueueCaps {
+    unsigned long long shard_cap, gq_cap;
+    bool retry;      // the capacities are a budget, not a bound: a block that overflows them is rendered again in parts
+};
+
+// For blocks of up to `samples` camera rays.  Where every hit spawns at most two rays (reflection + refraction) the
+// capacities are the worst case -- 2^(level-1) per camera ray at a level, 2^levels - 1 hits altogether -- up to four
+// levels; a glossy hit spawns 16 + 16 (main.cpp:177-257), which no capacity bounds: three such levels in a row get
+// room (32^2 per camera ray), and what outgrows that is split (see rt_render_rows_dev).
+QueueCaps queue_caps(const rt_context* ctx, const rt_render_params* p, unsigned long long samples)
+{
+    const int levels = ctx->has_bounce ? std::min(p->tracing_depth, rtr::MAX_LEVELS) : 1;
+    const bool glossy = ctx->has_glossy && levels > 1;
+    const unsigned long long cap_hits = samples << (glossy ? 10 : std::max(0, std::min(levels - 1, 3)));
+    const unsigned long long cap_gq = glossy ? cap_hits + cap_hits / 8 : samples * ((1ull << std::min(levels, 4)) - 1);
+    QueueCaps q;
+    // (shards fill nearly evenly -- producers pick them round-robin -- hence the slack)
+    q.shard_cap = (((cap_hits + rtq::SHARDS - 1) / rtq::SHARDS + 16384) + 63) & ~63ull;
+    q.gq_cap = (((cap_gq + rtq::SHARDS - 1) / rtq::SHARDS + 16384) + 63) & ~63ull;
+    q.retry = glossy || levels > 4;
+    // RT_SHARD_CAP=<slots>: smaller queues, to exercise the overflow handling (development aid)
+    if (const char* e = getenv("RT_SHARD_CAP")) q.shard_cap = q.gq_cap = std::max<unsigned long long>(64, (strtoull(e, nullptr, 10) + 63) & ~63ull);
+    return q;
+}
+
 template <class R>
-int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, double* d_acc, rtr::RenderCounters* host_ctr,
+int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, const QueueCaps& caps, double* d_acc, rtr::RenderCounters* host_ctr,
                  hipEvent_t ev_begin, hipEvent_t ev_end)
 {
-    const int rows = a.row_end - a.row_begin;
-    const unsigned long long samples = (unsigned long long)a.width * rows * (a.dof_samples > 1 ? a.aadepth * a.aadepth * a.dof_samples : a.aadepth);
     // (a scene of diffuse surfaces only queues no rays: one level, and the deeper launches are not made)
     const int levels = ctx->has_bounce ? std::min(p->tracing_depth, rtr::MAX_LEVELS) : 1;
-    // worst case: every hit of a level spawns two (reflection + refraction); the queues are split into
-    // shards of equal capacity that fill nearly evenly (producers pick shards round-robin), with slack
-    // (a glossy hit spawns 16 + 16 rays: such scenes are rendered in small row blocks with room for two glossy bounces in a row)
-    const unsigned long long cap_hits = samples << (ctx->has_glossy && levels > 1 ? 10 : std::max(0, std::min(levels - 1, 3)));
-    // (a multiple of 64: the gather queue is filled in whole windows of 64 slots)
-    unsigned long long shard_cap = (((cap_hits + rtq::SHARDS - 1) / rtq::SHARDS + 16384) + 63) & ~63ull;
-    // RT_SHARD_CAP=<slots>: a smaller queue, to exercise the overflow report (development aid)
-    if (const char* e = getenv("RT_SHARD_CAP")) shard_cap = std::max<unsigned long long>(64, (strtoull(e, nullptr, 10) + 63) & ~63ull);
-    const unsigned long long cap_total = shard_cap * rtq::SHARDS;
+    const unsigned long long shard_cap = caps.shard_cap, gq_cap = caps.gq_cap;
+    const unsigned long long cap_total = shard_cap * rtq::SHARDS, gq_total = gq_cap * rtq::SHARDS;
     int rc;
     if ((rc = ctx->hits_a.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
     if ((rc = ctx->hits_b.reserve(cap_total * sizeof(rtr::HitRec)))) return rc;
     if ((rc = ctx->rays.reserve(cap_total * sizeof(rtr::RayRec)))) return rc;
-    if ((rc = ctx->gq.reserve(cap_total * sizeof(rtg::GatherRec)))) return rc;
-    if ((rc = ctx->redo.reserve(cap_total * sizeof(uint32_t)))) return rc;
+    if ((rc = ctx->gq.reserve(gq_total * sizeof(rtg::GatherRec)))) return rc;
+    if ((rc = reserve_redo(ctx, gq_total))) return rc;
     TraceGeom g;
     if ((rc = trace_geometry<R>(ctx, ctx->n_nodes, &g, 16))) return rc;
     rtr::RenderCounters* ctr = (rtr::RenderCounters*)ctx->counters.p;
@@ -1500,8 +1561,8 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     // (the instrumented kernels exist for the double instantiation without depth of field, which is what measurements run)
     const bool count = p->count_work && sizeof(R) == sizeof(double) && a.dof_samples <= 1;
 #define RT_LEVELS(TRI, MODE)                                                                                                  \
-    (count ? launch_render_levels<double, TRI, MODE, true>(ctx, a, g, levels, shard_cap, ctr, d_acc)                           \
-           : launch_render_levels<R, TRI, MODE, false>(ctx, a, g, levels, shard_cap, ctr, d_acc))
+    (count ? launch_render_levels<double, TRI, MODE, true>(ctx, a, g, levels, shard_cap, gq_cap, ctr, d_acc)                   \
+           : launch_render_levels<R, TRI, MODE, false>(ctx, a, g, levels, shard_cap, gq_cap, ctr, d_acc))
     if (tri_only) {
         if (g.mode == rtk::TRAV_NODES) rc = RT_LEVELS(true, rtk::TRAV_NODES);
         else if (g.mode == rtk::TRAV_RETEST) rc = RT_LEVELS(true, rtk::TRAV_RETEST);
@@ -1522,8 +1583,8 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
         gp.norm = (double)(p->photon_num / 16) * 3.1415926;
         gp.photon_num = (double)p->photon_num;
         gp.seed = p->rng_seed;
-        if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, shard_cap, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, gp, d_acc,
-                                (uint32_t*)ctx->redo.p)))
+        if ((rc = launch_gather(ctx, (const rtg::GatherRec*)ctx->gq.p, &ctr->gather, gq_cap, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, ctr->tile_progress, gp,
+                                d_acc, (uint32_t*)ctx->redo.p, ctx->redo.bytes / sizeof(uint32_t))))
             return rc;
     }
     if (host_ctr) HIP_TRY(hipMemcpyAsync(host_ctr, ctr, sizeof(*host_ctr), hipMemcpyDeviceToHost, ctx->stream));
@@ -1566,17 +1627,26 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     int chunk_rows = (int)std::max<long long>(8, (max_samples / ((long long)p->width * per_pixel)) / 8 * 8);
     if ((long long)p->width * chunk_rows >= (1ll << 25)) return fail(RT_ERR_LIMIT, "width %d: a block of 8 rows exceeds 2^25 pixels", p->width);
     const size_t n_chunks = (size_t)((row_end - row_begin + chunk_rows - 1) / chunk_rows);
-    std::vector<rtr::RenderCounters> hc(n_chunks);
-    if (stats)
-        while (ctx->chunk_ev.size() < 2 * n_chunks) {
+    const QueueCaps caps = queue_caps(ctx, p, (unsigned long long)p->width * std::min(chunk_rows, row_end - row_begin) * per_pixel);
+    std::vector<rtr::RenderCounters> hc(caps.retry ? 0 : n_chunks);
+    if (stats || caps.retry)
+        while (ctx->chunk_ev.size() < 2 * (caps.retry ? 1 : n_chunks)) {
             hipEvent_t e;
             HIP_TRY(hipEventCreate(&e));
             ctx->chunk_ev.push_back(e);
         }
     rt_stats total;
     memset(&total, 0, sizeof total);
+    auto add_counters = [&](const rtr::RenderCounters& c) {
+        total.secondary_rays += c.secondary_rays;
+        for (int sh = 0; sh < rtq::SHARDS; sh++) total.gather_queries += c.gather.n[sh][1];
+        total.gather_single += c.n_redo;
+        total.inner_visits += c.work_inner;
+        total.prim_tests += c.work_prims;
+    };
     HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
     size_t ci = 0;
+    a.col_begin = 0; a.col_end = p->width;
     for (int r0 = row_begin; r0 < row_end; r0 += chunk_rows, ci++) {
         int r1 = std::min(row_end, r0 + chunk_rows);
         size_t npx = (size_t)p->width * (r1 - r0);
@@ -1588,11 +1658,54 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
             if ((rc = ctx->acc.reserve(npx * 3 * sizeof(double)))) return rc;
             acc = (double*)ctx->acc.p;
         }
-        a.row_begin = r0; a.row_end = r1;
-        hipEvent_t eb = stats ? ctx->chunk_ev[2 * ci] : nullptr, ee = stats ? ctx->chunk_ev[2 * ci + 1] : nullptr;
-        rc = p->precision == RT_F64 ? render_block<double>(ctx, a, p, acc, stats ? &hc[ci] : nullptr, eb, ee)
-                                    : render_block<float>(ctx, a, p, acc, stats ? &hc[ci] : nullptr, eb, ee);
-        if (rc) return rc;
+        if (!caps.retry) {
+            a.row_begin = r0; a.row_end = r1;
+            hipEvent_t eb = stats ? ctx->chunk_ev[2 * ci] : nullptr, ee = stats ? ctx->chunk_ev[2 * ci + 1] : nullptr;
+            rc = p->precision == RT_F64 ? render_block<double>(ctx, a, p, caps, acc, stats ? &hc[ci] : nullptr, eb, ee)
+                                        : render_block<float>(ctx, a, p, caps, acc, stats ? &hc[ci] : nullptr, eb, ee);
+            if (rc) return rc;
+        } else {
+            // The queues are a budget here.  A part whose rays outgrow them is split -- rows first, then columns, down
+            // to one tile of 8 x 8 pixels -- and rendered again: its first kernel starts the pixels' sums afresh, so
+            // nothing of the attempt that overflowed stays.  Each part is waited for, to learn how it went.
+            struct Part { int r0, r1, c0, c1; };
+            std::vector<Part> todo{{r0, r1, 0, p->width}};
+            while (!todo.empty()) {
+                const Part q = todo.back();
+                todo.pop_back();
+                a.row_begin = q.r0; a.row_end = q.r1; a.col_begin = q.c0; a.col_end = q.c1;
+                double* const acc_part = acc + (size_t)p->width * (q.r0 - r0) * 3;
+                rtr::RenderCounters c;
+                rc = p->precision == RT_F64 ? render_block<double>(ctx, a, p, caps, acc_part, &c, ctx->chunk_ev[0], ctx->chunk_ev[1])
+                                            : render_block<float>(ctx, a, p, caps, acc_part, &c, ctx->chunk_ev[0], ctx->chunk_ev[1]);
+                if (rc) return rc;
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                if (c.overflow_stack) return overflow_error(ctx, "traversal stack overflow");
+                if (c.overflow_queue) {
+                    unsigned long long latch[2];
+                    if ((rc = take_overflow_latch(ctx, latch))) return rc;       // (handled here: not an error of the frame)
+                    const int rows = q.r1 - q.r0, cols = q.c1 - q.c0;
+                    if (rows > 8) {
+                        const int mid = q.r0 + (rows / 2 + 7) / 8 * 8;
+                        todo.push_back({mid, q.r1, q.c0, q.c1});
+                        todo.push_back({q.r0, mid, q.c0, q.c1});
+                    } else if (cols > 8) {
+                        const int mid = q.c0 + (cols / 2 + 7) / 8 * 8;
+                        todo.push_back({q.r0, q.r1, mid, q.c1});
+                        todo.push_back({q.r0, q.r1, q.c0, mid});
+                    } else {
+                        return fail(RT_ERR_LIMIT, "the rays of one tile of 8 x 8 pixels overflow the queues (%llu slots a level): lower tracing_depth",
+                                    caps.shard_cap * rtq::SHARDS);
+                    }
+                    continue;
+                }
+                add_counters(c);
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->chunk_ev[0], ctx->chunk_ev[1]));
+                total.trace_kernel_ms += ms;
+            }
+            a.col_begin = 0; a.col_end = p->width;
+        }
         int threads = 256;
         hipLaunchKernelGGL(rtr::resolve_kernel, dim3((unsigned)((npx + threads - 1) / threads)), dim3(threads), 0, ctx->stream, (long long)npx, p->aadepth,
                            acc, d_rgb ? acc : nullptr, d_bgr8 ? d_bgr8 + off * 3 : nullptr);
@@ -1602,19 +1715,15 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (stats) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        for (size_t i = 0; i < ci; i++) {
+        for (size_t i = 0; i < hc.size(); i++) {
             if (hc[i].overflow_stack) return overflow_error(ctx, "traversal stack overflow");
             if (hc[i].overflow_queue) return overflow_error(ctx, "bounce/gather queue overflow");
-            total.secondary_rays += hc[i].secondary_rays;
-            for (int sh = 0; sh < rtq::SHARDS; sh++) total.gather_queries += hc[i].gather.n[sh][1];
-            total.gather_single += hc[i].n_redo;
-            total.inner_visits += hc[i].work_inner;
-            total.prim_tests += hc[i].work_prims;
+            add_counters(hc[i]);
         }
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         total.kernel_ms = ms;
-        for (size_t i = 0; i < ci; i++) {                            // trace + shade launches, summed over the row chunks
+        for (size_t i = 0; i < hc.size(); i++) {                     // trace + shade launches, summed over the row chunks
             HIP_TRY(hipEventElapsedTime(&ms, ctx->chunk_ev[2 * i], ctx->chunk_ev[2 * i + 1]));
             total.trace_kernel_ms += ms;
         }

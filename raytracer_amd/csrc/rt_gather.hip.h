@@ -756,18 +756,58 @@ __device__ __forceinline__ double unit_random(uint32_t a, uint32_t b, uint32_t s
     return ((double)x + 0.5) * (1.0 / 4294967296.0);
 }
 
+constexpr uint32_t REDO_EMPTY = 0xFFFFFFFFu;    // a list entry nobody has written yet (the list is all REDO_EMPTY between launches)
+
+// the estimate of one queued request, added to its pixel (one wave)
+__device__ __forceinline__ void answer_request(const PhotonMapView& pm, const PhotonMapView& vm, const GatherRec& r, const GatherParams& gp, Neighbour& nb, double* __restrict__ acc)
+{
+    const int lane = lane_id();
+    const Prof pf{nullptr};
+    const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, gp.front_cap, pf, &nb);
+    __builtin_amdgcn_wave_barrier();
+    double rgb[3];
+    float md2;
+    estimate_raw(pm, count, r.normal, r.color, gp.norm, rgb, &md2);
+    if ((r.flags & GATHER_SSS) && vm.n > 0) {                       // main.cpp:297-388
+        const float hp[3] = {(float)r.pos[0], (float)r.pos[1], (float)r.pos[2]};
+        double sss[3] = {0, 0, 0};
+        __builtin_amdgcn_wave_barrier();
+        int vc = knn_collect(vm, hp[0], hp[1], hp[2], gp.k, gp.r2, gp.front_cap, pf);
+        __builtin_amdgcn_wave_barrier();
+        volume_step(vm, vc, hp, r.color, 1.0, gp.photon_num, sss);
+        if (r.flags & GATHER_MARCH) {
+            double px = r.pos[0] + r.march[0] * 0.02, py = r.pos[1] + r.march[1] * 0.02, pz = r.pos[2] + r.march[2] * 0.02;   // main.cpp:341
+            double e_pass = 2.71828;
+            for (int pass = 1; pass < 3; pass++) {
+                __builtin_amdgcn_wave_barrier();
+                vc = knn_collect(vm, (float)px, (float)py, (float)pz, gp.k, gp.r2, gp.front_cap, pf);
+                __builtin_amdgcn_wave_barrier();
+                volume_step(vm, vc, hp, r.color, e_pass, gp.photon_num, sss);
+                // the stream is keyed by what identifies the request whatever the launch: pixel, hit point, pass
+                const uint32_t where = __float_as_uint(hp[0]) * 0x9E3779B1u ^ __float_as_uint(hp[1]) * 0x85EBCA77u ^ __float_as_uint(hp[2]) * 0xC2B2AE3Du;
+                double d = -log(unit_random(r.pixel, where + (uint32_t)pass, gp.seed)) / 200;   // main.cpp:374
+                px += r.march[0] * d; py += r.march[1] * d; pz += r.march[2] * d;
+                e_pass *= 2.71828;
+            }
+        }
+        rgb[0] += sss[0]; rgb[1] += sss[1]; rgb[2] += sss[2];      // main.cpp:389
+    }
+    clip3(rgb);                                                    // main.cpp:391
+    if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * (lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2])));
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Per-request consumer: acc[3*pixel..] += weight * clip(estimate) for the requests whose queue slots
 // are listed in `list` (those the group form hands over: subsurface materials, crowded or
 // incoherent groups).  One request per wave at a time.  Requests differ a lot in cost, so the
 // (single-wave) blocks of the persistent grid draw them from a shared counter -- several per draw
 // while plenty are left, one near the end; a request takes tens of microseconds, which keeps the
-// draw rate far below what one counter word sustains.
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_kernel(PhotonMapView pm, PhotonMapView vm, const GatherRec* __restrict__ recs, const uint32_t* __restrict__ list,
+// draw rate far below what one counter word sustains.  Every entry read is reset to REDO_EMPTY.
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_kernel(PhotonMapView pm, PhotonMapView vm, const GatherRec* __restrict__ recs, uint32_t* list,
                                                       const unsigned long long* n_list, unsigned long long* next, GatherParams gp,
                                                       double* __restrict__ acc)
 {
     const int lane = lane_id();
-    const Prof pf{nullptr};
     const unsigned long long n_all = *n_list;
     const uint32_t n = n_all > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_all;
     uint32_t q_end = 0;
@@ -782,40 +822,50 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         if (q0 >= n) break;
         q_end = q0 + want < n ? (uint32_t)q0 + want : n;
         for (uint32_t q = (uint32_t)q0; q < q_end; q++) {
-            const GatherRec& r = recs[list[q]];
-            const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, gp.front_cap, pf, &nb);
+            const uint32_t slot = list[q];
             __builtin_amdgcn_wave_barrier();
-            double rgb[3];
-            float md2;
-            estimate_raw(pm, count, r.normal, r.color, gp.norm, rgb, &md2);
-            if ((r.flags & GATHER_SSS) && vm.n > 0) {                       // main.cpp:297-388
-                const float hp[3] = {(float)r.pos[0], (float)r.pos[1], (float)r.pos[2]};
-                double sss[3] = {0, 0, 0};
-                __builtin_amdgcn_wave_barrier();
-                int vc = knn_collect(vm, hp[0], hp[1], hp[2], gp.k, gp.r2, gp.front_cap, pf);
-                __builtin_amdgcn_wave_barrier();
-                volume_step(vm, vc, hp, r.color, 1.0, gp.photon_num, sss);
-                if (r.flags & GATHER_MARCH) {
-                    double px = r.pos[0] + r.march[0] * 0.02, py = r.pos[1] + r.march[1] * 0.02, pz = r.pos[2] + r.march[2] * 0.02;   // main.cpp:341
-                    double e_pass = 2.71828;
-                    for (int pass = 1; pass < 3; pass++) {
-                        __builtin_amdgcn_wave_barrier();
-                        vc = knn_collect(vm, (float)px, (float)py, (float)pz, gp.k, gp.r2, gp.front_cap, pf);
-                        __builtin_amdgcn_wave_barrier();
-                        volume_step(vm, vc, hp, r.color, e_pass, gp.photon_num, sss);
-                        // the stream is keyed by what identifies the request whatever the launch: pixel, hit point, pass
-                        const uint32_t where = __float_as_uint(hp[0]) * 0x9E3779B1u ^ __float_as_uint(hp[1]) * 0x85EBCA77u ^ __float_as_uint(hp[2]) * 0xC2B2AE3Du;
-                        double d = -log(unit_random(r.pixel, where + (uint32_t)pass, gp.seed)) / 200;   // main.cpp:374
-                        px += r.march[0] * d; py += r.march[1] * d; pz += r.march[2] * d;
-                        e_pass *= 2.71828;
-                    }
-                }
-                rgb[0] += sss[0]; rgb[1] += sss[1]; rgb[2] += sss[2];      // main.cpp:389
-            }
-            clip3(rgb);                                                    // main.cpp:391
-            if (lane < 3) atomicAdd(&acc[3 * (size_t)r.pixel + lane], r.weight * (lane == 0 ? rgb[0] : (lane == 1 ? rgb[1] : rgb[2])));
-            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) list[q] = REDO_EMPTY;
+            answer_request(pm, vm, recs[slot], gp, nb, acc);
         }
+    }
+}
+
+// The same consumer started ALONGSIDE the group kernel, on a few blocks per CU: it takes the hand-overs as they are
+// written (an entry is there once it is no longer REDO_EMPTY) and so fills the compute units the group kernel's last
+// windows leave idle.  It draws from the same counter as the launch above, which follows the group kernel and takes
+// what is left.  A wave that has drawn an entry not yet written waits for it, or for the group kernel's last window:
+// after that the list is final, and an entry still empty lies beyond its end.  A wave of this kernel stays only if
+// every wave of the group kernel has begun (windows_done[1] counts them), i.e. it is not holding a place one of those
+// still needs: the group kernel is launched first and fills the device, and these waves move in as its waves leave.
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_alongside_kernel(PhotonMapView pm, PhotonMapView vm, const GatherRec* __restrict__ recs, uint32_t* list,
+                                                      uint32_t list_cap, const rtq::Counts* cnt, unsigned long long shard_cap, const unsigned long long* windows_done,
+                                                      unsigned tile_waves, unsigned long long* next, GatherParams gp, double* __restrict__ acc)
+{
+    const int lane = lane_id();
+    const unsigned long long n_windows = rtq::map_units(cnt, shard_cap, WAVE).total;
+    if (__hip_atomic_load(windows_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tile_waves) return;
+    Neighbour nb{0.f, 0.f, 0.f, -1.f};
+    while (true) {
+        unsigned long long q0 = 0;
+        if (lane == 0) q0 = atomicAdd(next, 1ull);
+        q0 = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(q0 >> 32)) << 32) | __builtin_amdgcn_readfirstlane((unsigned)q0);
+        if (q0 >= list_cap) break;
+        uint32_t slot;
+        while (true) {
+            slot = __hip_atomic_load(&list[q0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (slot != REDO_EMPTY) break;
+            if (__hip_atomic_load(windows_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n_windows) {
+                __threadfence();
+                slot = __hip_atomic_load(&list[q0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // final now
+                break;
+            }
+            __builtin_amdgcn_s_sleep(64);
+        }
+        slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+        if (slot == REDO_EMPTY) break;
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) list[q0] = REDO_EMPTY;
+        answer_request(pm, vm, recs[slot], gp, nb, acc);
     }
 }
 

@@ -33,7 +33,7 @@ constexpr int T_PIVOTS = 512;     // inner-node pivots inside a group's box
 // most T_LEAVES * 64 + T_PIVOTS photons.)
 constexpr size_t T_TABLE_BYTES = offsetof(WaveLds, f_lo) - offsetof(WaveLds, key);
 static_assert(offsetof(WaveLds, key) == 0 && T_BINS * WAVE * 2 <= T_TABLE_BYTES && T_CRIT * WAVE * 4 <= T_TABLE_BYTES, "the per-lane tables fit");
-static_assert(T_LEAVES * 64 + T_PIVOTS < 65536 && T_BINS % 2 == 0, "histogram counts fit 16 bits; bins 2i and 2i + 1 share a word");
+static_assert(T_LEAVES * 64 + T_PIVOTS < 65536, "histogram counts fit 16 bits");
 
 struct TileLds {
     uint32_t leaf[T_LEAVES];      // first photon << 7 | photons (<= 64): the leaves some request's ball touches
@@ -73,8 +73,9 @@ struct TileArgs {
     const rtq::Counts* cnt;          // n[s][0]: slots appended to shard s (a multiple of 64)
     unsigned long long shard_cap;
     unsigned long long* next;        // draw counter
-    uint32_t* redo;                  // slots of the requests left to the per-query kernel
+    uint32_t* redo;                  // slots of the requests left to the per-query kernel (entries not yet written hold REDO_EMPTY)
     unsigned long long* n_redo;
+    unsigned long long* windows_done;   // [0] windows finished, their hand-overs written; [1] waves of this kernel that have begun (the per-query kernel that runs alongside goes by both)
     int all_redo;                    // nonzero: hand every request to the per-query kernel (comparison runs)
     unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
 };
@@ -224,12 +225,24 @@ __device__ __forceinline__ D2x4 quad_d2(const Xyz4& c, float qx, float qy, float
 // Histogram bin of a squared distance: bin 0 holds everything below `lower` (distances the triangle inequality
 // already puts inside the set), bins 1 .. T_BINS - 2 are linear over [lower, bound), the last bin takes everything
 // from `bound` on (and the filler photons of a short step), so no photon needs a comparison with the bound.
-// Monotone in d2.  scale = shell_scale(bound, lower).
-__device__ __forceinline__ float shell_scale(float bound, float lower) { return ((float)(T_BINS - 2) * 0.999999f) / (bound - lower); }
-__device__ __forceinline__ f2 shell_pos(f2 d2, float lower, float scale) { return (d2 - f2{lower, lower}) * f2{scale, scale} + f2{1.f, 1.f}; }
+// The position d2 * scale + offset is monotone in d2 as evaluated (a product with a positive factor, then a sum), which
+// is all the selection needs; rounding moves a bin's edge by a few units in the last place of the position.
+struct Shell { float scale, offset; };
+__device__ __forceinline__ Shell shell_of(float bound, float lower)
+{
+    Shell sh;
+    sh.scale = ((float)(T_BINS - 2) * 0.999999f) / (bound - lower);
+    sh.offset = 1.f - lower * sh.scale;
+    return sh;
+}
+__device__ __forceinline__ f2 shell_pos(f2 d2, const Shell& sh) { return d2 * f2{sh.scale, sh.scale} + f2{sh.offset, sh.offset}; }
 __device__ __forceinline__ int shell_bin_of(float pos) { return (int)__builtin_amdgcn_fmed3f(pos, 0.f, (float)(T_BINS - 1)); }
-// The histogram of a lane: word (b >> 1) * 64 + lane holds the count of bin b in its low half (b even) or its high half.
-__device__ __forceinline__ void hist_add(uint32_t* mine, int bin) { atomicAdd(mine + (bin >> 1) * WAVE, (bin & 1) * 0xFFFFu + 1u); }
+// The histograms: lanes l and l + 32 share the word bin * 32 + l, the lower lane counting in its low half.  (A
+// wave's LDS operation goes through in two halves of 32 lanes, so the two never meet in one pass.)
+__device__ __forceinline__ uint32_t* hist_mine(uint32_t* cell, int lane) { return cell + (lane & 31); }
+__device__ __forceinline__ uint32_t hist_unit(int lane) { return lane < 32 ? 1u : 0x10000u; }
+__device__ __forceinline__ void hist_add(uint32_t* mine, uint32_t unit, int bin) { atomicAdd(mine + bin * 32, unit); }
+__device__ __forceinline__ uint32_t hist_count(const uint32_t* mine, int lane, int bin) { const uint32_t w = mine[bin * 32]; return lane < 32 ? w & 0xFFFFu : w >> 16; }
 
 // Copy to `dst` the leaves of `src` that some lane has to look at photon by photon: those with a photon
 // possibly at a squared distance in [lo_lim, hi_lim] from the lane's point (hi_lim < 0: the lane takes no
@@ -270,8 +283,7 @@ __device__ __attribute__((noinline)) int select_leaves(const float* __restrict__
 __device__ __forceinline__ uint32_t* lane_tables() { return reinterpret_cast<uint32_t*>(g_L.key); }   // [row][lane] over the candidates' distances
 
 // 3a: the lane's histogram (see hist_add) of the squared distances from its point to the photons of the list
-__device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float lower, float scale,
-                                                    int n_leaf, int n_piv)
+__device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, Shell sh, int n_leaf, int n_piv)
 {
     uint32_t* const cell = lane_tables();
     const int lane = lane_id();
@@ -280,7 +292,8 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
     __builtin_amdgcn_wave_barrier();
     n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);      // (the same in every lane: let the compiler know)
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
-    uint32_t* const mine = cell + lane;
+    uint32_t* const mine = hist_mine(cell, lane);
+    const uint32_t unit = hist_unit(lane);
     int n = 0, at = 0, n_next = 0;
     float4 p = n_steps > 0 ? step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at) : float4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < n_steps; s++, n = n_next) {
@@ -292,11 +305,11 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
         // sets take turns, so nothing is copied)
         auto bin4 = [&](const Xyz4& c) {
             const D2x4 d = quad_d2(c, qx, qy, qz);
-            const f2 at_a = shell_pos(d.a, lower, scale), at_b = shell_pos(d.b, lower, scale);
-            hist_add(mine, shell_bin_of(at_a.x));
-            hist_add(mine, shell_bin_of(at_a.y));
-            hist_add(mine, shell_bin_of(at_b.x));
-            hist_add(mine, shell_bin_of(at_b.y));
+            const f2 at_a = shell_pos(d.a, sh), at_b = shell_pos(d.b, sh);
+            hist_add(mine, unit, shell_bin_of(at_a.x));
+            hist_add(mine, unit, shell_bin_of(at_a.y));
+            hist_add(mine, unit, shell_bin_of(at_b.x));
+            hist_add(mine, unit, shell_bin_of(at_b.y));
         };
         Xyz4 c0 = quad_load(0), c1;
         for (int j0 = 0; j0 < n_now; j0 += 8) {
@@ -309,9 +322,9 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
     __builtin_amdgcn_wave_barrier();
 }
 
-// 3b: cell[i][lane] = the i-th squared distance of the lane that falls into its bin `crit` (< 0: the lane takes
-// no part); returns their number
-__device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, float lower, float scale, int crit,
+// 3b: cell[i][lane] = the i-th squared distance of the lane that falls into its bin `crit` (1 .. T_BINS - 2; < 0: the
+// lane takes no part); returns their number
+__device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, Shell sh, int crit,
                                                    int n_leaf, int n_piv)
 {
     uint32_t* const cell = lane_tables();
@@ -319,7 +332,13 @@ __device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ po
     int cnt = 0;
     n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);      // (the same in every lane: let the compiler know)
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
-    const float crit_f = (float)crit;
+    // A position lies in bin `crit` (1 <= crit <= T_BINS - 2) when pos - crit is in [0, 1).  The difference is exact there
+    // (both are multiples of 2^-23 below 128), and a float in [0, 1) is one whose bit pattern, read as an unsigned
+    // number, is below that of 1.0: negative values and everything from 1.0 on compare above.  An idle lane subtracts
+    // a number no position reaches.
+    const float crit_f = crit >= 1 ? (float)crit : 1.0e30f;
+    const f2 crit_2 = {crit_f, crit_f};
+    constexpr uint32_t ONE = 0x3F800000u;
     int n = 0, at = 0, n_next = 0;
     float4 p = n_steps > 0 ? step_photons(pos, leaf, 0, n_leaf, n_piv, lane, n, at) : float4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < n_steps; s++, n = n_next) {
@@ -327,21 +346,26 @@ __device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ po
         const int n_now = __builtin_amdgcn_readfirstlane(n);
         // the next step's photons are on their way while this step's are used
         p = step_photons(pos, leaf, s + 1 < n_steps ? s + 1 : s, n_leaf, n_piv, lane, n_next, at);      // (unconditional: a fetch inside a branch is waited for at its end)
-        Xyz4 c = quad_load(0);
-        for (int j0 = 0; j0 < n_now; j0 += 4) {
-            const Xyz4 c_now = c;
-            c = quad_load((j0 + 4) & (WAVE - 1));
-            const D2x4 d = quad_d2(c_now, qx, qy, qz);
-            const f2 at_a = shell_pos(d.a, lower, scale), at_b = shell_pos(d.b, lower, scale);
-            // (the bin of a position is its integer part clamped to the table: compared as floats, one operation each)
-            const bool h0 = floorf(__builtin_amdgcn_fmed3f(at_a.x, 0.f, (float)(T_BINS - 1))) == crit_f, h1 = floorf(__builtin_amdgcn_fmed3f(at_a.y, 0.f, (float)(T_BINS - 1))) == crit_f;
-            const bool h2 = floorf(__builtin_amdgcn_fmed3f(at_b.x, 0.f, (float)(T_BINS - 1))) == crit_f, h3 = floorf(__builtin_amdgcn_fmed3f(at_b.y, 0.f, (float)(T_BINS - 1))) == crit_f;
-            if (__ballot(h0 || h1 || h2 || h3)) {           // rare: a few dozen photons per request
-                if (h0 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.x); cnt++; }
-                if (h1 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.y); cnt++; }
-                if (h2 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.x); cnt++; }
-                if (h3 && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.y); cnt++; }
+        // (two register sets take turns: a set is read from LDS while the other is worked on)
+        auto pick4 = [&](const Xyz4& c) {
+            const D2x4 d = quad_d2(c, qx, qy, qz);
+            const f2 at_a = shell_pos(d.a, sh), at_b = shell_pos(d.b, sh);
+            const f2 t_a = at_a - crit_2, t_b = at_b - crit_2;
+            const uint32_t u0 = __float_as_uint(t_a.x), u1 = __float_as_uint(t_a.y), u2 = __float_as_uint(t_b.x), u3 = __float_as_uint(t_b.y);
+            const uint32_t least = min(min(u0, u1), min(u2, u3));
+            if (__ballot(least < ONE)) {           // rare: a few dozen photons per request
+                if (u0 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.x); cnt++; }
+                if (u1 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.y); cnt++; }
+                if (u2 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.x); cnt++; }
+                if (u3 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.y); cnt++; }
             }
+        };
+        Xyz4 c0 = quad_load(0), c1;
+        for (int j0 = 0; j0 < n_now; j0 += 8) {
+            c1 = quad_load(j0 + 4);
+            pick4(c0);
+            c0 = quad_load((j0 + 8) & (WAVE - 1));
+            if (j0 + 4 < n_now) pick4(c1);
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -386,14 +410,16 @@ __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ po
             const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)at;
             b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
         }
-        Xyz4 c = quad_load(0);
-        for (int j0 = 0; j0 < n_now; j0 += 4) {
-            const Xyz4 c_now = c;
-            c = quad_load((j0 + 4) & (WAVE - 1));
-            const D2x4 d = quad_d2(c_now, qx, qy, qz);
-            // power and direction of the four photons: fetched with the coordinates, not inside the branch that uses them
-            const float4 pr4 = *reinterpret_cast<const float4*>(sa + j0), pg4 = *reinterpret_cast<const float4*>(sa + WAVE + j0), pb4 = *reinterpret_cast<const float4*>(sa + 2 * WAVE + j0);
-            const float4 ux4 = *reinterpret_cast<const float4*>(sa + 3 * WAVE + j0), uy4 = *reinterpret_cast<const float4*>(sa + 4 * WAVE + j0), uz4 = *reinterpret_cast<const float4*>(sa + 5 * WAVE + j0);
+        // power and direction of four photons are fetched with the coordinates, not inside the branch that uses them; two
+        // register sets take turns, one being read from LDS while the other is worked on
+        struct Aux4 { float4 pr, pg, pb, ux, uy, uz; };
+        auto aux_load = [&](int j) {
+            return Aux4{*reinterpret_cast<const float4*>(sa + j), *reinterpret_cast<const float4*>(sa + WAVE + j), *reinterpret_cast<const float4*>(sa + 2 * WAVE + j),
+                        *reinterpret_cast<const float4*>(sa + 3 * WAVE + j), *reinterpret_cast<const float4*>(sa + 4 * WAVE + j), *reinterpret_cast<const float4*>(sa + 5 * WAVE + j)};
+        };
+        auto sum4 = [&](const Xyz4& c, const Aux4& a) {
+            const D2x4 d = quad_d2(c, qx, qy, qz);
+            const float4 &pr4 = a.pr, &pg4 = a.pg, &pb4 = a.pb, &ux4 = a.ux, &uy4 = a.uy, &uz4 = a.uz;
             if (TIES) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
@@ -432,6 +458,14 @@ __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ po
                     s2 += (double)(b.x + b.y);
                 }
             }
+        };
+        Xyz4 c0 = quad_load(0), c1;
+        Aux4 a0 = aux_load(0), a1;
+        for (int j0 = 0; j0 < n_now; j0 += 8) {
+            c1 = quad_load(j0 + 4); a1 = aux_load(j0 + 4);
+            sum4(c0, a0);
+            c0 = quad_load((j0 + 8) & (WAVE - 1)); a0 = aux_load((j0 + 8) & (WAVE - 1));
+            if (j0 + 4 < n_now) sum4(c1, a1);
         }
     }
     return Sum3{s0, s1, s2};
@@ -443,6 +477,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const int lane = lane_id();
     const rtq::Map map = rtq::map_units(ta.cnt, ta.shard_cap, WAVE);
     const uint32_t n_windows = map.total;
+    if (lane == 0) atomicAdd(ta.windows_done + 1, 1ull);
     unsigned long long pr[TP_SLOTS] = {};
     const unsigned long long t_begin = ta.prof ? clock64() : 0ull;
 #define TILE_PROF(slot, expr) do { if (ta.prof) { const unsigned long long t_ = clock64(); expr; pr[slot] += clock64() - t_; } else { expr; } } while (0)
@@ -541,18 +576,20 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             n_leaf = select_leaves(pm.leaf_box, g_T.leaf, g_T.leaf, qx, qy, qz, 0.f, act ? bound : -1.f, n_leaf, &n_out);
             pr[TP_ROUNDS]++; pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_leaf + (n_piv + WAVE - 1) / WAVE;
 
-            const float scale = shell_scale(bound, lower);
+            const Shell sh = shell_of(bound, lower);
             // ---- 3a. per-lane histogram of the squared distances below the lane's bound
             // leaves that lie inside every request's inner ball count as a whole; the others go photon by photon
             int n_inside;
             const int n_hist = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, act ? lower : 3.0e38f, act ? 3.0e38f : -1.f, n_leaf, &n_inside);
-            TILE_PROF(TP_HIST, pass_hist(pm.pos, g_T.part, qx, qy, qz, lower, scale, n_hist, n_piv));
+            TILE_PROF(TP_HIST, pass_hist(pm.pos, g_T.part, qx, qy, qz, sh, n_hist, n_piv));
             pr[TP_N_HIST] += n_hist + (n_piv + WAVE - 1) / WAVE;
-            if (act) cell[lane] += (uint32_t)n_inside;             // (bin 0: the low half of word 0)
+            uint32_t* const mine = hist_mine(cell, lane);
+            if (act) hist_add(mine, hist_unit(lane) * (uint32_t)n_inside, 0);
             // the bin holding the lane's k-th smallest distance (or its largest, if fewer than k lie within the bound)
+            __builtin_amdgcn_wave_barrier();
             uint32_t total = 0;                                   // (the last bin holds what lies beyond the bound)
 #pragma unroll 4
-            for (int b = 0; b < T_BINS / 2; b++) { const uint32_t w = cell[b * WAVE + lane]; total += (w & 0xFFFFu) + (b < T_BINS / 2 - 1 ? w >> 16 : 0u); }      // (bins 2b, 2b + 1)
+            for (int b = 0; b < T_BINS - 1; b++) total += hist_count(mine, lane, b);
             const uint32_t k_eff = total < (uint32_t)gp.k ? total : (uint32_t)gp.k;
             // a bound derived from the neighbour must contain k photons; if it somehow does not, the per-query kernel decides
             TILE_COUNT(TP_R_SHORT, act && total < (uint32_t)gp.k && bound < gp.r2);
@@ -562,29 +599,26 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             {
                 uint32_t cum = 0;
 #pragma unroll 4
-                for (int w = 0; w < T_BINS / 2; w++) {
-                    const uint32_t both = cell[w * WAVE + lane];
-#pragma unroll
-                    for (int half = 0; half < 2; half++) {
-                        const int b = 2 * w + half;
-                        const uint32_t h = half ? both >> 16 : both & 0xFFFFu;
-                        if (b < T_BINS - 1 && crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
-                        cum += h;
-                    }
+                for (int b = 0; b < T_BINS - 1; b++) {
+                    const uint32_t h = hist_count(mine, lane, b);
+                    if (crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
+                    cum += h;
                 }
             }
-            TILE_COUNT(TP_R_CROWD, act && in_bin > (uint32_t)T_CRIT);
-            if (act && in_bin > (uint32_t)T_CRIT) { redo = true; act = false; }
+            // (k photons already inside the inner radius: the range was guessed too high -- the rigorous range never is)
+            const bool crowded = act && k_eff > 0 && (in_bin > (uint32_t)T_CRIT || crit == 0);
+            TILE_COUNT(TP_R_CROWD, crowded);
+            if (crowded) { redo = true; act = false; }
             const bool some = act && k_eff > 0;
             const int need = (int)(k_eff - below);                 // 1-based rank of the k-th smallest inside its bin
             __builtin_amdgcn_wave_barrier();
             // ---- 3b. the distances of that bin, ranked
             int cnt;
             // only the leaves that reach into some request's critical shell can hold a distance of its bin
-            const float shell_lo = crit > 0 ? lower + (float)(crit - 1) / scale : 0.f, shell_hi = crit > 0 ? lower + (float)crit / scale : lower;
+            const float shell_lo = crit > 0 ? lower + (float)(crit - 1) / sh.scale : 0.f, shell_hi = crit > 0 ? lower + (float)crit / sh.scale : lower;
             const int n_crit = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, some ? shell_lo * 0.9999f : 3.0e38f, some ? shell_hi * 1.0001f : -1.f, n_leaf,
                                              &n_out);
-            TILE_PROF(TP_CRIT, cnt = pass_crit(pm.pos, g_T.part, qx, qy, qz, lower, scale, some ? crit : -1, n_crit, n_piv));
+            TILE_PROF(TP_CRIT, cnt = pass_crit(pm.pos, g_T.part, qx, qy, qz, sh, some ? crit : -1, n_crit, n_piv));
             pr[TP_N_CRIT] += n_crit + (n_piv + WAVE - 1) / WAVE;
             const unsigned long long t_rank = ta.prof ? clock64() : 0ull;
             const int max_cnt = (int)wave_max_f((float)cnt);
@@ -644,8 +678,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             const int leader = __builtin_ctzll(m_redo);
             if (lane == leader) at = atomicAdd(ta.n_redo, (unsigned long long)__builtin_popcountll(m_redo));
             at = ((unsigned long long)(unsigned)__shfl((unsigned)(at >> 32), leader) << 32) | (unsigned)__shfl((unsigned)at, leader);
-            if (redo) ta.redo[at + prefix_rank(m_redo)] = (uint32_t)(slot0 + lane);
+            if (redo) __hip_atomic_store(&ta.redo[at + prefix_rank(m_redo)], (uint32_t)(slot0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        __threadfence();                                        // the entries are visible before the window counts as done
+        if (lane == 0) atomicAdd(ta.windows_done, 1ull);
         __builtin_amdgcn_wave_barrier();
     }
 #undef TILE_PROF

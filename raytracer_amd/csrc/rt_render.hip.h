@@ -82,6 +82,7 @@ struct RenderCounters {
     unsigned long long next_gather;     // draw counter of the per-request gather kernel
     unsigned long long next_window;     // draw counter of the group gather kernel
     unsigned long long n_redo;          // requests the group kernel left to the per-request kernel
+    unsigned long long tile_progress[2];   // of the group gather kernel: [0] windows finished (their hand-overs are written), [1] waves that have begun
     unsigned long long work_inner, work_prims;   // inner-node visits and primitive tests (counting instantiations only)
 };
 
@@ -94,6 +95,7 @@ struct ShadeData {
 struct RenderArgs {
     double cam_pos[3], cam_dir[3], cam_right[3], cam_down[3];
     int width, height, row_begin, row_end;
+    int col_begin, col_end;   // the columns this launch renders (a block of rows is split by columns when its rays outgrow the queues)
     int band_rows, n_parts, part;
     int aadepth;
     double accuracy;
@@ -124,13 +126,13 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
     unsigned long long ovf_queue = 0;
     rtk::WorkCount wc;
     const int rows = a.row_end - a.row_begin;
-    const int tiles_x = (a.width + 7) >> 3, tiles_y = (rows + 7) >> 3;
+    const int tiles_x = (a.col_end - a.col_begin + 7) >> 3, tiles_y = (rows + 7) >> 3;
     // one 8x8 tile and one of its aadepth sample columns per wave (the waves of a tile are neighbours in a block,
     // so they share its nodes and triangles in L1); the dispatcher balances the load
     int tx, ty, aax;
     if (rtk::tile_of_wave<MODE == rtk::TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, (unsigned)a.aadepth, &aax)) {
-        int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
-        bool inside = x < a.width && yl < rows;
+        int x = a.col_begin + tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
+        bool inside = x < a.col_end && yl < rows;
         int yc = a.row_begin + yl;
         int y = a.band_rows > 0 ? ((yc / a.band_rows) * a.n_parts + a.part) * a.band_rows + yc % a.band_rows : yc;
         // the pixel's accumulator starts at zero (the kernels that add to it run after this one): no separate fill pass
@@ -211,7 +213,7 @@ __device__ __forceinline__ void push_rays(RayRec* q, rtq::Counts* cnt, unsigned 
 // One recursion level of getColorAt for every queued hit, up to the point where it would call Shoot.
 __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a, int level, int last_level, const HitRec* __restrict__ in,
                                                       RayRec* __restrict__ rays, rtg::GatherRec* __restrict__ gq, unsigned long long shard_cap,
-                                                      RenderCounters* ctr)
+                                                      unsigned long long gq_cap, RenderCounters* ctr)
 {
     const int lane = threadIdx.x & 63;
     unsigned long long ovf_queue = 0;
@@ -357,7 +359,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
             }
             push_rays(rays, &ctr->rays[level], shard_cap, want, next, &ovf_queue);
         }
-        rtg::push_window(gq, &ctr->gather, shard_cap, want_g, g, &ovf_queue);
+        rtg::push_window(gq, &ctr->gather, gq_cap, want_g, g, &ovf_queue);      // (the gather queue takes requests from every level: a capacity of its own)
     }
     if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(ctr, 1); }
 }

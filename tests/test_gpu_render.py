@@ -339,6 +339,55 @@ def test_render_glossy_materials(gpu_ctx):
     assert np.abs(rgb2 - rgb)[balls].max() > 1e-3 and np.abs(rgb2 - rgb)[~balls].max() < 1e-9
 
 
+def _glossy_panes_scene(api):
+    api.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0, -0.7, 0))
+    # two panes of glossy glass between the camera and the box: every pixel sees the first, and the rays that pass it
+    # meet the second, whose reflections meet the first again
+    api.add_plane((1.0, 0.0, 0.0), 2.0, (1.0, 1.0, 1.0, 1.887654))
+    api.add_plane((1.0, 0.0, 0.0), 1.8, (1.0, 1.0, 1.0, 1.887654))
+    api.add_cornell()
+    api.build_bvh()
+    return api
+
+
+def test_render_glossy_glass_filling_the_frame(gpu_ctx, monkeypatch):
+    """Glossy glass in every pixel at the default depth of 4: each hit spawns 16 + 16 rays (main.cpp:177-257) and the
+    reflected ones meet the glass again, so a pixel ends in thousands of rays -- far more than the ray queues of a
+    block of rows hold.  The frame is then rendered in parts (rows, then columns) instead of failing, and comes out
+    as the oracle's and the same whatever the queues' size."""
+    s = _glossy_panes_scene(rt.Scene())
+    orc = _glossy_panes_scene(Oracle())
+    gpu_ctx.upload(s)
+    s.emit_photons(5000, seed=3)
+    ph = s.photons_get(0)
+    gpu_ctx.photons_upload(ph)
+    orc.photons_set(np.c_[ph, np.zeros(len(ph))], 0)
+    orc.build_kdtree()
+    w, h = 48, 32
+    p = rt.default_params(width=w, height=h, photon_num=5000, photon_use=20, rng_seed=99)
+    assert p.tracing_depth == 4
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    rgb, bgr, st = gpu_ctx.render(cam, p)
+    ids, _, _, _ = gpu_ctx.trace_primary(cam, rt.default_params(width=w, height=h))
+    assert len(np.unique(ids)) == 1 and ids.min() >= 0                              # the first pane, everywhere
+    assert st.secondary_rays > 2000 * w * h                                          # far beyond 1024 slots per camera ray
+    orc.params.photon_num = 5000
+    orc.params.photon_use = 20
+    orc.params.counter_rng = 1
+    orc.params.rng_seed = 99
+    ref, nrays = orc.render(w, h, CAM, threads=8)
+    a, b = u8(rgb), u8(ref)
+    within = (np.abs(a - b).max(-1) <= 1).mean()
+    print(f"glossy panes: within 1 LSB {within:.5f}, max {np.abs(a - b).max()}, rays {st.secondary_rays} (oracle {nrays}), mean {b.mean():.2f}")
+    assert b.max() > 10 and within >= 0.999
+    # smaller queues: more parts, the same frame (sums of the same terms in another order)
+    monkeypatch.setenv("RT_SHARD_CAP", "20000")
+    rgb2, _, st2 = gpu_ctx.render(cam, p)
+    monkeypatch.delenv("RT_SHARD_CAP")
+    assert st2.secondary_rays == st.secondary_rays and st2.gather_queries == st.gather_queries
+    assert np.abs(rgb2 - rgb).max() < 1e-9 * max(1.0, np.abs(rgb).max())
+
+
 @pytest.mark.parametrize("aadepth,dof", [(1, 8), (2, 3)])
 def test_render_depth_of_field(gpu_ctx, aadepth, dof):
     """Depth of field (main.cpp:792-826, DOF_SAMPLE > 1): lens positions from the counter-based stream, the
