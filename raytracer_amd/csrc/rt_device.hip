@@ -127,6 +127,7 @@ struct rt_context {
     bool has_glossy = false;  // some material takes the 16-sample loops of main.cpp:177-257
     bool has_bounce = false;  // some material reflects, refracts or scatters below the surface (special != 0): hits can queue rays
     DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
+    DevBuf ctr_log;           // the counter blocks of a frame's row chunks, fetched once at its end
     // photon maps in HBM (0 surface, 1 volume)
     DevBuf ph_pos[2], ph_aux[2], ph_axis[2], ph_order[2], ph_box[2];
     DevBuf ph_src[2];         // photon records (9 doubles each) of a map built on the device, in list order
@@ -362,7 +363,7 @@ void rt_context_destroy(rt_context* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
-                      &ctx->texels, &ctx->counters, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
+                      &ctx->texels, &ctx->counters, &ctx->ctr_log, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
                       &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->redo, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
                       &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1], &ctx->ph_box[0], &ctx->ph_box[1], &ctx->ph_src[0], &ctx->ph_src[1],
                       &ctx->ph_raw[0], &ctx->ph_raw[1], &ctx->kd_work})
@@ -1426,6 +1427,7 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     rtg::GatherParams gpt = gp;
     if (const char* e = getenv("RT_GATHER_OPT_RANGE")) gpt.opt_range = (float)atof(e);      // tuning aids
     if (const char* e = getenv("RT_GATHER_MIN_LANES")) gpt.min_lanes = atoi(e);
+
     rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, windows_done, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
                      prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));      // (the queue and the counters are ready here)
@@ -1447,10 +1449,10 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
         const double nr = (double)std::max<unsigned long long>(1, v[rtg::TP_ROUNDS]);
         fprintf(stderr, "group gather (k=%d): %llu windows, %llu rounds, %.1f requests and %.1f steps of 64 photons per round (hist %.1f, crit %.1f, sum %.1f steps); "
                         "cycles per round: kth %.0f, walk %.0f, hist %.0f, crit %.0f, rank %.0f, sum %.0f; requests handed on: %llu other materials, %llu in small rounds, "
-                        "%llu box too large, %llu range too low, %llu range too high or crowded bin, %llu left after the last round; busy cycles per wave: mean %.0f, longest %llu\n",
+                        "%llu box too large, %llu range too low, %llu range too high or crowded bin, %llu left after the last round, %llu ties to split; busy cycles per wave: mean %.0f, longest %llu\n",
                 gp.k, v[rtg::TP_WINDOWS], v[rtg::TP_ROUNDS], v[rtg::TP_LANES] / nr, v[rtg::TP_STEPS] / nr, v[rtg::TP_N_HIST] / nr, v[rtg::TP_N_CRIT] / nr, v[rtg::TP_N_SUM] / nr,
                 v[rtg::TP_KTH] / nr, v[rtg::TP_WALK] / nr, v[rtg::TP_HIST] / nr, v[rtg::TP_CRIT] / nr, v[rtg::TP_RANK] / nr, v[rtg::TP_SUM] / nr, v[rtg::TP_R_FLAGS],
-                v[rtg::TP_R_FEW], v[rtg::TP_R_WALK], v[rtg::TP_R_SHORT], v[rtg::TP_R_CROWD], v[rtg::TP_R_LEFT], v[rtg::TP_BUSY] / (ctx->num_cus * 8.0), v[rtg::TP_BUSY_MAX]);
+                v[rtg::TP_R_FEW], v[rtg::TP_R_WALK], v[rtg::TP_R_SHORT], v[rtg::TP_R_CROWD], v[rtg::TP_R_LEFT], v[rtg::TP_R_TIE], v[rtg::TP_BUSY] / (ctx->num_cus * 8.0), v[rtg::TP_BUSY_MAX]);
     }
     hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, d_redo,
                        (const unsigned long long*)n_redo, next_gather, gp, d_acc);
@@ -1539,7 +1541,7 @@ QueueCaps queue_caps(const rt_context* ctx, const rt_render_params* p, unsigned 
 }
 
 template <class R>
-int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, const QueueCaps& caps, double* d_acc, rtr::RenderCounters* host_ctr,
+int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_params* p, const QueueCaps& caps, double* d_acc, rtr::RenderCounters* ctr_copy,
                  hipEvent_t ev_begin, hipEvent_t ev_end)
 {
     // (a scene of diffuse surfaces only queues no rays: one level, and the deeper launches are not made)
@@ -1587,7 +1589,9 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
                                 d_acc, (uint32_t*)ctx->redo.p, ctx->redo.bytes / sizeof(uint32_t))))
             return rc;
     }
-    if (host_ctr) HIP_TRY(hipMemcpyAsync(host_ctr, ctr, sizeof(*host_ctr), hipMemcpyDeviceToHost, ctx->stream));
+    // (a copy of the counters for the caller: into device memory where the caller does not wait for this block -- a copy
+    // to the host would hold up the launches of the next one)
+    if (ctr_copy) HIP_TRY(hipMemcpyAsync(ctr_copy, ctr, sizeof(*ctr_copy), hipMemcpyDefault, ctx->stream));
     return RT_OK;
 }
 
@@ -1629,6 +1633,8 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     const size_t n_chunks = (size_t)((row_end - row_begin + chunk_rows - 1) / chunk_rows);
     const QueueCaps caps = queue_caps(ctx, p, (unsigned long long)p->width * std::min(chunk_rows, row_end - row_begin) * per_pixel);
     std::vector<rtr::RenderCounters> hc(caps.retry ? 0 : n_chunks);
+    if (stats && !caps.retry && (rc = ctx->ctr_log.reserve(n_chunks * sizeof(rtr::RenderCounters)))) return rc;
+    rtr::RenderCounters* const d_log = (rtr::RenderCounters*)ctx->ctr_log.p;
     if (stats || caps.retry)
         while (ctx->chunk_ev.size() < 2 * (caps.retry ? 1 : n_chunks)) {
             hipEvent_t e;
@@ -1661,8 +1667,8 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
         if (!caps.retry) {
             a.row_begin = r0; a.row_end = r1;
             hipEvent_t eb = stats ? ctx->chunk_ev[2 * ci] : nullptr, ee = stats ? ctx->chunk_ev[2 * ci + 1] : nullptr;
-            rc = p->precision == RT_F64 ? render_block<double>(ctx, a, p, caps, acc, stats ? &hc[ci] : nullptr, eb, ee)
-                                        : render_block<float>(ctx, a, p, caps, acc, stats ? &hc[ci] : nullptr, eb, ee);
+            rc = p->precision == RT_F64 ? render_block<double>(ctx, a, p, caps, acc, stats ? d_log + ci : nullptr, eb, ee)
+                                        : render_block<float>(ctx, a, p, caps, acc, stats ? d_log + ci : nullptr, eb, ee);
             if (rc) return rc;
         } else {
             // The queues are a budget here.  A part whose rays outgrow them is split -- rows first, then columns, down
@@ -1714,6 +1720,7 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     }
     HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (stats) {
+        if (!hc.empty()) HIP_TRY(hipMemcpyAsync(hc.data(), d_log, hc.size() * sizeof(rtr::RenderCounters), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         for (size_t i = 0; i < hc.size(); i++) {
             if (hc[i].overflow_stack) return overflow_error(ctx, "traversal stack overflow");

@@ -89,8 +89,12 @@ struct Cand {
     int count;       // entries in g_L.key / g_idx
     float bound;     // candidates need d2 < bound
     int tight;       // the keys reach up to the bound (a select or a neighbour's hint set it): the
-                     // select may bin over [0, bound] without looking for the largest key first
+                     // select may bin over [0, bound] without looking for the largest key first.  Such a bound
+                     // is INCLUSIVE: a photon found later at exactly the k-th distance is still a candidate, so
+                     // which of several photons at that distance stay does not depend on the order they are met in
+                     // (select_k decides by tree position).  The search radius itself is exclusive (Kdtree.cpp:77,82).
 };
+__device__ __forceinline__ bool within(float d2, const Cand& c) { return c.tight ? d2 <= c.bound : d2 < c.bound; }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -134,8 +138,8 @@ __device__ __forceinline__ void locate_bin(uint32_t want, uint32_t& bin, uint32_
 }
 
 // Bit pattern of the k-th smallest key by most-significant-digit radix passes (any key distribution).
-// `want` returns how many entries equal to it belong to the k smallest.
-__device__ uint32_t radix_threshold(int count, int k, int& want)
+// `want` returns how many entries equal to it belong to the k smallest, `n_eq` how many entries equal it.
+__device__ uint32_t radix_threshold(int count, int k, int& want, int& n_eq)
 {
     WaveLds& L = g_L;
     const int lane = lane_id();
@@ -152,6 +156,7 @@ __device__ uint32_t radix_threshold(int count, int k, int& want)
         uint32_t bin, below, in_bin;
         locate_bin((uint32_t)want, bin, below, in_bin);
         want -= (int)below;
+        n_eq = (int)in_bin;                 // (after the last pass: the entries with exactly this bit pattern)
         prefix |= bin << (8 * pass);
         pmask |= 255u << (8 * pass);
         __builtin_amdgcn_wave_barrier();
@@ -203,7 +208,7 @@ __device__ __attribute__((noinline)) Cand select_k(int count, int k, float key_l
     locate_bin((uint32_t)k, bin, below, in_bin);
     __builtin_amdgcn_wave_barrier();
     uint32_t T;
-    int want;
+    int want, n_eq = 0;
     if (in_bin <= (uint32_t)WAVE) {
         // the bin's entries, in buffer order, into L.hist (its counts are no longer needed)
         int m = 0;
@@ -231,9 +236,36 @@ __device__ __attribute__((noinline)) Cand select_k(int count, int k, float key_l
         int src = __builtin_ctzll(__ballot(lane < m && rank == need - 1));
         T = __shfl(e, src);
         want = __builtin_popcountll(__ballot(lane < m && e == T && rank < need));
+        n_eq = __builtin_popcountll(__ballot(lane < m && e == T));
         __builtin_amdgcn_wave_barrier();
     } else {
-        T = radix_threshold(count, k, want);
+        T = radix_threshold(count, k, want, n_eq);
+    }
+    // Several photons at exactly the k-th distance of which only some belong to the set (float distances of photons a
+    // rounding error apart coincide): those at the lowest tree positions stay, whatever order the walk met them in.
+    bool by_position = false;
+    uint32_t last_position = 0;
+    if (IDS && n_eq > want && n_eq <= 256) {
+        int m = 0;
+        for (int base = 0; base < count; base += WAVE) {
+            const int j = base + lane;
+            const bool eq = j < count && __float_as_uint(L.key[j]) == T;
+            const unsigned long long me = __ballot(eq);
+            if (eq) L.hist[m + (int)prefix_rank(me)] = g_idx[j];
+            m += __builtin_popcountll(me);
+        }
+        __builtin_amdgcn_wave_barrier();
+        bool found = false;
+        uint32_t mine = 0;
+        for (int t = lane; t < n_eq; t += WAVE) {
+            const uint32_t p = L.hist[t];
+            int rank = 0;
+            for (int j = 0; j < n_eq; j++) rank += L.hist[j] < p ? 1 : 0;
+            if (rank == want - 1) { found = true; mine = p; }
+        }
+        const unsigned long long mf = __ballot(found);      // tree positions are distinct: exactly one lane
+        if (mf) { last_position = (uint32_t)__shfl((int)mine, __builtin_ctzll(mf)); by_position = true; }
+        __builtin_amdgcn_wave_barrier();
     }
     // T = bit pattern of the k-th smallest key; `want` = how many entries equal to T to keep
     // stable in-place compaction (outputs never pass the read cursor: a block of entries is in registers
@@ -253,7 +285,7 @@ __device__ __attribute__((noinline)) Cand select_k(int count, int k, float key_l
             bool less = ku[u] < T;
             bool eq = ku[u] == T;
             unsigned long long meq = __ballot(eq);
-            bool keep = less || (eq && (eq_taken + (int)prefix_rank(meq)) < want);
+            bool keep = less || (eq && (by_position ? id[u] <= last_position : (eq_taken + (int)prefix_rank(meq)) < want));
             unsigned long long mk = __ballot(keep);
             if (keep) {
                 int p = out + (int)prefix_rank(mk);
@@ -332,7 +364,7 @@ __device__ __attribute__((noinline)) Cand scan_steps(PhotonMapView pm, float qx,
                         float dx = qx - px[u], dy = qy - py[u], dz = qz - pz[u];
                         d2 = dx * dx + dy * dy + dz * dz;
                     }
-                    append<IDS>(c.count, valid[u] && d2 < c.bound, d2, (uint32_t)id[u]);
+                    append<IDS>(c.count, valid[u] && within(d2, c), d2, (uint32_t)id[u]);
                 }
             }
         }
@@ -387,7 +419,7 @@ __device__ __attribute__((noinline)) Cand walk_serial(PhotonMapView pm, float qx
             float dx = qx - px, dy = qy - py, dz = qz - pz;
             float d2 = dx * dx + dy * dy + dz * dz;
             make_room<IDS>(c, k, WAVE, pf);
-            append<IDS>(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119)
+            append<IDS>(c.count, lane == 0 && within(d2, c), d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119)
             float split = ax == 0 ? px : (ax == 1 ? py : pz);
             float delta = (ax == 0 ? qx : (ax == 1 ? qy : qz)) - split;
             int nlo, nhi, flo, fhi;
@@ -438,7 +470,7 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
         float px = pv.x, py = pv.y, pz = pv.z;
         float dx = qx - px, dy = qy - py, dz = qz - pz;
         float d2 = dx * dx + dy * dy + dz * dz;
-        append<IDS>(c.count, lane == 0 && d2 < c.bound, d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119); < 32 of these
+        append<IDS>(c.count, lane == 0 && within(d2, c), d2, (uint32_t)mid);   // the pivot itself (Kdtree.cpp:119); < 32 of these
         float split = ax == 0 ? px : (ax == 1 ? py : pz);
         float delta = (ax == 0 ? qx : (ax == 1 ? qy : qz)) - split;
         int nlo, nhi, flo, fhi;
@@ -485,7 +517,7 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
             // it never exceeds the distance of any photon inside.
             const float* b = pm.leaf_box + 6 * (size_t)(rlo >> 5);
             float ex = fmaxf(fmaxf(b[0] - qx, qx - b[3]), 0.f), ey = fmaxf(fmaxf(b[1] - qy, qy - b[4]), 0.f), ez = fmaxf(fmaxf(b[2] - qz, qz - b[5]), 0.f);
-            if (!(ex * ex + ey * ey + ez * ez < c.bound)) is_leaf = false;
+            if (!within(ex * ex + ey * ey + ez * ez, c)) is_leaf = false;
         }
         const bool is_inner = live && !small;
         int mid = 0, nlo = 0, nhi = 0, flo = 0, fhi = 0;
@@ -504,7 +536,7 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
             dd = delta * delta;
         }
         make_room<IDS>(c, k, WAVE, pf);
-        append<IDS>(c.count, is_inner && d2 < c.bound, d2, (uint32_t)mid);
+        append<IDS>(c.count, is_inner && within(d2, c), d2, (uint32_t)mid);
         const bool push_far = is_inner && fhi > flo && dd <= c.bound;
         const bool push_near = is_inner && nhi > nlo;
         const unsigned long long m_far = __ballot(push_far), m_near = __ballot(push_near), m_leaf = __ballot(is_leaf);

@@ -80,7 +80,7 @@ struct TileArgs {
     unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
 };
 enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_N_HIST, TP_N_CRIT, TP_N_SUM,
-                TP_R_FLAGS, TP_R_FEW, TP_R_WALK, TP_R_SHORT, TP_R_CROWD, TP_R_LEFT, TP_BUSY, TP_BUSY_MAX, TP_SLOTS };      // TP_R_*: requests handed on, by reason
+                TP_R_FLAGS, TP_R_FEW, TP_R_WALK, TP_R_SHORT, TP_R_CROWD, TP_R_LEFT, TP_R_TIE, TP_BUSY, TP_BUSY_MAX, TP_SLOTS };      // TP_R_*: requests handed on, by reason
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // two photons per packed instruction
 
@@ -374,17 +374,14 @@ __device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ po
 
 struct Sum3 { double s0, s1, s2; };
 
-// 3c: the sums of main.cpp:262-291 (power * |cosine| * weight per channel) over the photons with d2 < t_k and the
-// first want_eq with d2 == t_k.  TIES = false: every photon at exactly the k-th distance belongs to the set (the
-// caller has counted them), so the test is one comparison.
-template <bool TIES>
+// 3c: the sums of main.cpp:262-291 (power * |cosine| * weight per channel) over the photons with d2 <= t_k: every
+// photon at exactly the k-th distance belongs to the set (the caller has counted them), so the test is one comparison.
 __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ pos, const float* __restrict__ aux, const uint32_t* leaf, float qx, float qy, float qz, float t_k,
-                                                   int want_eq, bool some, float nx, float ny, float nz, int n_leaf, int n_piv)
+                                                   bool some, float nx, float ny, float nz, int n_leaf, int n_piv)
 {
     const int lane = lane_id();
     const TermCoef tc = term_coef(t_k);
     double s0 = 0, s1 = 0, s2 = 0;
-    int eq_seen = 0;
     n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);      // (the same in every lane: let the compiler know)
     const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
     const float lim = some ? t_k : -1.f;
@@ -420,25 +417,7 @@ __device__ __attribute__((noinline)) Sum3 pass_sum(const float4* __restrict__ po
         auto sum4 = [&](const Xyz4& c, const Aux4& a) {
             const D2x4 d = quad_d2(c, qx, qy, qz);
             const float4 &pr4 = a.pr, &pg4 = a.pg, &pb4 = a.pb, &ux4 = a.ux, &uy4 = a.uy, &uz4 = a.uz;
-            if (TIES) {
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const float d2 = u == 0 ? d.a.x : (u == 1 ? d.a.y : (u == 2 ? d.b.x : d.b.y));
-                    bool in = d2 < lim;
-                    if (d2 == lim) { in = eq_seen < want_eq; eq_seen++; }
-                    if (__ballot(in)) {
-                        if (in) {
-                            const float pr = u == 0 ? pr4.x : (u == 1 ? pr4.y : (u == 2 ? pr4.z : pr4.w)), pg = u == 0 ? pg4.x : (u == 1 ? pg4.y : (u == 2 ? pg4.z : pg4.w));
-                            const float pb = u == 0 ? pb4.x : (u == 1 ? pb4.y : (u == 2 ? pb4.z : pb4.w)), ux = u == 0 ? ux4.x : (u == 1 ? ux4.y : (u == 2 ? ux4.z : ux4.w));
-                            const float uy = u == 0 ? uy4.x : (u == 1 ? uy4.y : (u == 2 ? uy4.z : uy4.w)), uz = u == 0 ? uz4.x : (u == 1 ? uz4.y : (u == 2 ? uz4.z : uz4.w));
-                            const float sc = photon_term(tc, d2, nx, ny, nz, ux, uy, uz);
-                            s0 += (double)(pr * sc);             // main.cpp:286 without the hit colour, which the caller multiplies in
-                            s1 += (double)(pg * sc);
-                            s2 += (double)(pb * sc);
-                        }
-                    }
-                }
-            } else {
+            {
                 // Four photons at a time without a branch per photon: a photon outside the lane's ball contributes a
                 // factor 0.  The four terms of a channel are added in float before they join the double sum.
                 const bool in0 = d.a.x <= lim, in1 = d.a.y <= lim, in2 = d.b.x <= lim, in3 = d.b.y <= lim;
@@ -648,20 +627,22 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             }
             const float t_k = __uint_as_float(t_bits);             // the k-th distance = maxDistSqr (main.cpp:266-267)
             const int want_eq = need - less;                       // photons at exactly that distance that belong to the set
+            // Several photons at exactly the k-th distance of which only some belong: the per-request kernel decides which
+            // (it has a rule that does not depend on the order the photons are met in); here every one at that distance counts.
+            const bool split_tie = some && equal != want_eq;
+            TILE_COUNT(TP_R_TIE, split_tie);
+            if (split_tie) redo = true;
+            const bool summed = some && !split_tie;
             __builtin_amdgcn_wave_barrier();
             if (ta.prof) pr[TP_RANK] += clock64() - t_rank;
             // ---- 3c. the estimate over the set (main.cpp:262-295)
             Sum3 sum;
             const unsigned long long t_sum = ta.prof ? clock64() : 0ull;
-            n_leaf = select_leaves(pm.leaf_box, g_T.leaf, g_T.leaf, qx, qy, qz, 0.f, some ? t_k : -1.f, n_leaf, &n_out);      // the final balls are smaller than the bounds
-            // (photons at exactly the k-th distance: if some request must leave one of them out, the pass counts them as it goes)
-            if (__ballot(some && equal != want_eq))
-                sum = pass_sum<true>(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv);
-            else
-                sum = pass_sum<false>(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, want_eq, some, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv);
+            n_leaf = select_leaves(pm.leaf_box, g_T.leaf, g_T.leaf, qx, qy, qz, 0.f, summed ? t_k : -1.f, n_leaf, &n_out);      // the final balls are smaller than the bounds
+            sum = pass_sum(pm.pos, pm.aux, g_T.leaf, qx, qy, qz, t_k, summed, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2], n_leaf, n_piv);
             pr[TP_N_SUM] += n_leaf + (n_piv + WAVE - 1) / WAVE;
             if (ta.prof) pr[TP_SUM] += clock64() - t_sum;
-            if (some) {
+            if (summed) {
                 const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
                 double rgb[3] = {r.color[0] * sum.s0 * sc, r.color[1] * sum.s1 * sc, r.color[2] * sum.s2 * sc};
                 clip3(rgb);                                        // main.cpp:391

@@ -381,7 +381,7 @@ def test_render_glossy_glass_filling_the_frame(gpu_ctx, monkeypatch):
     print(f"glossy panes: within 1 LSB {within:.5f}, max {np.abs(a - b).max()}, rays {st.secondary_rays} (oracle {nrays}), mean {b.mean():.2f}")
     assert b.max() > 10 and within >= 0.999
     # smaller queues: more parts, the same frame (sums of the same terms in another order)
-    monkeypatch.setenv("RT_SHARD_CAP", "20000")
+    monkeypatch.setenv("RT_SHARD_CAP", "40000")
     rgb2, _, st2 = gpu_ctx.render(cam, p)
     monkeypatch.delenv("RT_SHARD_CAP")
     assert st2.secondary_rays == st.secondary_rays and st2.gather_queries == st.gather_queries
