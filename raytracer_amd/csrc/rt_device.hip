@@ -118,6 +118,7 @@ struct rt_context {
     std::vector<hipEvent_t> chunk_ev;   // begin / end of the trace + shade launches of every row chunk of a timed frame
     // flattened scene in HBM, both instantiations
     DevBuf nodes64, prims64, planes64, nodes32, prims32, planes32, objs, texdesc, texels;
+    DevBuf obj_live;          // one byte per object: its hits spawn rays (special > 0)
     rtf::SceneView<double> v64{};
     rtf::SceneView<float> v32{};
     int depth = 0;
@@ -362,7 +363,7 @@ void rt_context_destroy(rt_context* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
-    for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->texdesc,
+    for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->obj_live, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->ctr_log, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
                       &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->redo, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
                       &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1], &ctx->ph_box[0], &ctx->ph_box[1], &ctx->ph_src[0], &ctx->ph_src[1],
@@ -871,13 +872,18 @@ int upload_shading(rt_context* ctx, const rth::Scene& s)
 {
     int rc;
     std::vector<rtf::ObjShade> sh(s.objects.size());
+    std::vector<unsigned char> live(sh.size());
     ctx->has_glossy = ctx->has_bounce = false;
     for (size_t i = 0; i < sh.size(); i++) {
         sh[i] = s.objects[i].sh;
         if (sh[i].color[3] != 0.0) ctx->has_bounce = true;
         if (rtm::glossy_special(sh[i].color[3])) ctx->has_glossy = true;
+        // (a textured triangle takes its colour from the map, whose `special` is 0: see rtm::obj_color)
+        const bool textured = sh[i].kind == rtf::PRIM_TRI && sh[i].has_texture && sh[i].map >= 0;
+        live[i] = sh[i].color[3] > 0 && !textured ? 1 : 0;
     }
     if ((rc = upload(ctx->objs, sh, ctx->stream))) return rc;
+    if ((rc = upload(ctx->obj_live, live, ctx->stream))) return rc;
     std::vector<rtf::TexDesc> td;
     std::vector<double> pool;
     for (const auto& t : s.textures) {
@@ -1622,11 +1628,19 @@ int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_pa
     a.aadepth = p->aadepth;
     a.accuracy = p->accuracy;
     a.head_quirk = p->head_quirk; a.use_photon_map = p->use_photon_map;
+    a.obj_live = p->use_photon_map ? nullptr : (const unsigned char*)ctx->obj_live.p;
     a.seed = p->rng_seed;
     a.dof_samples = p->dof_samples; a.focal_len = p->focal_len; a.aperture = p->aperture;
 
     // row chunks bound the queue memory: at most ~4M distinct camera rays per chunk (16M when no surface can queue a ray)
-    const long long max_samples = ctx->has_glossy ? 32ll << 10 : (ctx->has_bounce ? 4ll << 20 : 16ll << 20);
+    long long max_samples = ctx->has_glossy ? 32ll << 10 : (ctx->has_bounce ? 4ll << 20 : 16ll << 20);
+    if (ctx->has_bounce && !ctx->has_glossy) {
+        // where memory is plentiful a 3840 x 2160 frame is one chunk (its queues take about 30 GB): every chunk pays the
+        // ramp-up and the tail of each of its launches
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b + ctx->hits_a.bytes + ctx->hits_b.bytes + ctx->rays.bytes + ctx->gq.bytes > (96ull << 30))
+            max_samples = 17ll << 19;
+    }
     const long long per_pixel = p->dof_samples > 1 ? (long long)p->aadepth * p->aadepth * p->dof_samples : p->aadepth;
     int chunk_rows = (int)std::max<long long>(8, (max_samples / ((long long)p->width * per_pixel)) / 8 * 8);
     if ((long long)p->width * chunk_rows >= (1ll << 25)) return fail(RT_ERR_LIMIT, "width %d: a block of 8 rows exceeds 2^25 pixels", p->width);

@@ -103,6 +103,11 @@ struct RenderArgs {
     uint32_t seed;      // of the counter-based draws (glossy rays, lens jitter)
     int dof_samples;    // main.cpp:35 (1: no depth of field)
     double focal_len, aperture;
+    // Without a photon map the shading of a hit does one thing only: spawn the rays of a reflecting or refracting surface
+    // (main.cpp:260: the diffuse term IS the photon estimate).  obj_live[object] != 0 marks the objects whose hits spawn
+    // rays; hits on the others are not queued for a shading pass that would drop them.  Every ray is traced as before.
+    // Null when a photon map is in use: every hit is shaded then.
+    const unsigned char* obj_live;
 };
 
 __device__ __forceinline__ int rtk_wave_max(int v)
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
                     R d[3] = {(R)dj.x, (R)dj.y, (R)dj.z};
                     R dist = R(1e9);
                     int id = rtk::trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack, &wc);
-                    if (id >= 0 && (double)dist > a.accuracy) {                      // main.cpp:815-820
+                    if (id >= 0 && (double)dist > a.accuracy && (!a.obj_live || a.obj_live[id])) {   // main.cpp:815-820
                         double t = (double)dist;
                         // the jittered origin, but the un-jittered direction (main.cpp:821-822)
                         rec.pos[0] = org.x + dd.x * t; rec.pos[1] = org.y + dd.y * t; rec.pos[2] = org.z + dd.z * t;
@@ -401,6 +406,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
             n_secondary++;
             double t = (double)dist;
             bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:193,245
+            if (go && a.obj_live) go = a.obj_live[a.head_quirk ? ray.obj : io] != 0;
             if (go) {
                 rtm::D3 org = {ray.org[0], ray.org[1], ray.org[2]}, dir = {ray.cont[0], ray.cont[1], ray.cont[2]};
                 const bool refract = (ray.pixel & RAY_REFRACT) != 0;
