@@ -260,7 +260,10 @@ int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int6
 /* The pixel loop of main.cpp:735-861 for rows [row_begin,row_end): primary rays, BVH::Shoot,
  * getColorAt (main.cpp:158-392: reflection / refraction bounce queue + photon gather) and the
  * quantiser of saveBmp (IO.cpp:55-65).  d_rgb: (rows*width*3) doubles (may be NULL);
- * d_bgr8: (rows*width*3) bytes B,G,R (may be NULL).  Enqueued, not synchronised. */
+ * d_bgr8: (rows*width*3) bytes B,G,R (may be NULL).  Enqueued, not synchronised -- except for scenes
+ * whose rays no queue size bounds (a glossy material: 16 + 16 rays per hit, main.cpp:177-257; or
+ * tracing_depth > 4): those are rendered in parts sized by what the ray queues hold, each part waited
+ * for, a part that overflows being split (rows, then columns, down to one 8 x 8 tile) and rendered again. */
 int rt_render_rows_dev(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end,
                        double* d_rgb, uint8_t* d_bgr8, rt_stats* stats);
 int rt_render_rows(rt_context* ctx, const rt_camera* cam, const rt_render_params* p, int row_begin, int row_end,
