@@ -1431,6 +1431,10 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     if (prof && (rc = ctx->st_aux.reserve(rtg::TP_SLOTS * 8))) return rc;
     if (prof) HIP_TRY(hipMemsetAsync(ctx->st_aux.p, 0, rtg::TP_SLOTS * 8, ctx->stream));
     rtg::GatherParams gpt = gp;
+    // The relative range around the centre's k-th distance searched for a neighbour's: it has to cover the scatter of a
+    // k-th distance (about 1 / (2 sqrt(k)) of it) and the change of the photon density across a ball; what it misses
+    // is answered per request.  Measured on the water frame: k = 1000 fastest at 0.15 (0.3: +11 %, 0.1: +3 %), k = 100 at 0.25 - 0.3.
+    gpt.opt_range = std::min(0.5f, 0.1f + 1.5f / sqrtf((float)gp.k));
     if (const char* e = getenv("RT_GATHER_OPT_RANGE")) gpt.opt_range = (float)atof(e);      // tuning aids
     if (const char* e = getenv("RT_GATHER_MIN_LANES")) gpt.min_lanes = atoi(e);
 
