@@ -147,9 +147,12 @@ __device__ __forceinline__ float entry_floor(R t)
     return f;
 }
 
+// any_hit: the caller only asks WHETHER something lies within `dist` (an occlusion query): the walk ends at the first
+// primitive found.  The same boxes are entered in the same order and the same primitive tests decide, so "something
+// was hit" is the answer the full walk gives; which primitive, and how far, is then not the closest one.
 template <class R, bool COUNT = false, bool TRI_ONLY = false, int MODE = TRAV_PLAIN>
 __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R& dist, const LaneStack& st, uint32_t* overflow,
-                         WorkCount* wc = nullptr)
+                         WorkCount* wc = nullptr, bool any_hit = false)
 {
     if (d[0] != d[0]) return -1;   // BVH.cpp:110-115
     int hit = -1;
@@ -193,6 +196,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                         if (h1) { cur = c1; continue; }
                     } else {
                         test_leaf<R, COUNT, TRI_ONLY>(sv.prims, cur, o, d, dist, hit, wc);
+                        if (any_hit && hit >= 0) break;
                     }
                     bool found = false;
                     while (sp > 0) {
@@ -227,6 +231,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                     if (have) {
                         if (cur & rtf::LEAF_BIT) {
                             test_leaf<R, COUNT, TRI_ONLY>(sv.prims, cur, o, d, dist, hit, wc);
+                            if (any_hit && hit >= 0) break;
                         } else {
                             const rtf::Node<R>& nd = sv.nodes[cur];
                             if (COUNT) wc->inner++;
@@ -259,7 +264,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
         }
     }
     // planes: side list, same accept rule (no counterpart in the reference, where Plane is abstract)
-    for (int k = 0; k < sv.n_planes; k++) {
+    for (int k = 0; k < sv.n_planes && !(any_hit && hit >= 0); k++) {
         const rtf::Prim<R>& p = sv.planes[k];
         R t = rtm::plane_intersect<R>(p.a, p.e1[0], o, d);
         if (t >= R(0) && t < dist) { dist = t; hit = (int)p.id; }
@@ -427,7 +432,8 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
                     R o2[3] = {(R)so.x, (R)so.y, (R)so.z};
                     R d2[3] = {(R)L.x, (R)L.y, (R)L.z};
                     R range = (R)(len - 1e-4);
-                    sid = trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o2, d2, range, st, &overflow, &wc);
+                    // (the folded form reports occlusion only: the walk may stop at the first occluder)
+                    sid = trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o2, d2, range, st, &overflow, &wc, a.shadow == 2 && !shadow_ids);
                     n_shadow++;
                 }
                 if (shadow_ids) shadow_ids[px] = sid;

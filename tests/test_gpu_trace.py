@@ -198,6 +198,31 @@ def test_shadow_rays_match_oracle(gpu_ctx, scenes):
     assert st.shadow_rays == int(hit.sum())
 
 
+@pytest.mark.parametrize("scene", ["teapot_normal", "water"])
+@pytest.mark.parametrize("precision", [rt.RT_F64, rt.RT_F32])
+def test_folded_shadow_bit_is_the_occlusion_of_the_shadow_ids(gpu_ctx, scenes, scene, precision):
+    """shadow_rays = 2 without a shadow-id buffer: one word per pixel, bit 30 set where the shadow ray is occluded.  That
+    walk may stop at the first occluder; its answer is `shadow id >= 0` of the full walk, pixel for pixel."""
+    import ctypes
+    gpu_ctx.upload(scenes[scene])
+    w, h = 640, 360
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    light = np.array([0.1, 0.9, 0.0])
+    ids, _, sh, st1 = gpu_ctx.trace_primary(cam, rt.default_params(width=w, height=h, shadow_rays=1, light_pos=light, precision=precision))
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")                                # the runtime the library itself uses
+    d_ids = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_ids), ctypes.c_size_t(w * h * 4)) == 0
+    st2 = gpu_ctx.trace_primary_dev(cam, rt.default_params(width=w, height=h, shadow_rays=2, light_pos=light, precision=precision), (0, h), d_ids, None, None)
+    folded = np.zeros(w * h, np.int32)
+    assert hip.hipMemcpy(folded.ctypes.data_as(ctypes.c_void_p), d_ids, ctypes.c_size_t(w * h * 4), 2) == 0      # device to host
+    assert hip.hipFree(d_ids) == 0
+    bit = 1 << 30
+    assert eq(np.where(folded >= 0, folded & ~bit, folded), ids)
+    occluded = (folded >= 0) & ((folded & bit) != 0)
+    assert eq(occluded, sh >= 0) and 0.02 < occluded.mean() < 0.9
+    assert st2.shadow_rays == st1.shadow_rays
+
+
 def test_mixed_primitives_and_planes(gpu_ctx):
     """Spheres (with the reference's root quirks) inside the BVH, a plane in the side list."""
     def fill(api):
