@@ -1437,6 +1437,7 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     gpt.opt_range = std::min(0.5f, 0.1f + 1.5f / sqrtf((float)gp.k));
     if (const char* e = getenv("RT_GATHER_OPT_RANGE")) gpt.opt_range = (float)atof(e);      // tuning aids
     if (const char* e = getenv("RT_GATHER_MIN_LANES")) gpt.min_lanes = atoi(e);
+    if (const char* e = getenv("RT_GATHER_ROUNDS")) gpt.max_rounds = atoi(e);
 
     rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, windows_done, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
                      prof ? (unsigned long long*)ctx->st_aux.p : nullptr};

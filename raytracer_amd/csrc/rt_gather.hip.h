@@ -643,6 +643,7 @@ struct GatherParams {
     double photon_num;   // PHOTONMUM as a double: the volume normaliser divides in floating point (main.cpp:332)
     uint32_t seed;       // of the march's step lengths (main.cpp:374)
     float opt_range = 0.3f;   // group form: widest relative range around the centre's k-th distance searched for a neighbour's (>= 1: the rigorous range); the launch sets it from k
+    int max_rounds = 6;       // group form: rounds per window before the rest is handed on
     int min_lanes = 0;        // group form: fewest requests worth a round of their own (0: chosen from k)
 };
 

@@ -485,7 +485,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         // those still waiting; what is left after ROUNDS rounds, and rounds of only a few requests, go to the
         // per-request kernel.
         // (measured on the water frame: fastest at 12 requests for k = 1000 -- 8: +8 %, 16: +2 %, 24: +9 % -- and flat from 4 to 8 for k = 100)
-        constexpr int ROUNDS = 6;
+        const int ROUNDS = gp.max_rounds;
         const int MIN_LANES = gp.min_lanes > 0 ? gp.min_lanes : (gp.k >= 400 ? 12 : 6);
         for (int round = 0; round < ROUNDS; round++) {
             const unsigned long long m_todo = __ballot(todo);
