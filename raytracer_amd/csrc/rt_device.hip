@@ -1503,7 +1503,8 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
                            (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
     HIP_TRY(hipGetLastError());
     // persistent grids for the queue consumers (their work counts live in device memory)
-    const int trace_blocks_cu = std::max(1, std::min<int>((int)(160 * 1024 / std::max<size_t>(g.lds, 1)), 12 / wpb));
+    // (the queue tracer is held to 128 registers: four waves per SIMD, sixteen per CU)
+    const int trace_blocks_cu = std::max(1, std::min<int>((int)(160 * 1024 / std::max<size_t>(g.lds, 1)), 16 / wpb));
     const int trace_blocks = ctx->num_cus * trace_blocks_cu;
     const int shade_blocks = ctx->num_cus * 4;
     rtr::HitRec* qin = (rtr::HitRec*)ctx->hits_a.p;

@@ -370,10 +370,10 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
 }
 
 // Shoot for every queued ray of a level; hits become the next level's queue (main.cpp:190-199, 242-250).
-// (The draw loop around the traversal costs this kernel about 45 registers -- 144 instead of 100 in f64, three waves per
-// SIMD.  Holding it to 128 with amdgpu_waves_per_eu spills 12 of them and was measured slower on both test frames.)
+// (The draw loop around the traversal costs this kernel about 45 registers.  It is held to 128 -- four waves per SIMD --
+// which the compiler reaches without spilling once the ray record is read in two parts, see below.)
 template <class R, bool TRI_ONLY, int MODE, bool COUNT = false>
-__global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneView<R> sv, RenderArgs a, int level, const RayRec* __restrict__ rays,
+__global__ __launch_bounds__(rtk::MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void trace_queue_kernel(rtf::SceneView<R> sv, RenderArgs a, int level, const RayRec* __restrict__ rays,
                                                                     HitRec* __restrict__ out, unsigned long long shard_cap, RenderCounters* ctr,
                                                                     int cap, int n_nodes)
 {
@@ -397,25 +397,30 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void trace_queue_kernel(rtf::SceneV
         HitRec next;
         bool want = false;
         if (st.lane < (int)in_window) {
-            RayRec ray = rays[(unsigned long long)shard * shard_cap + i];
-            ray.pixel &= HIT_PIXEL_MASK | RAY_REFRACT;
-            R o[3] = {(R)ray.org[0], (R)ray.org[1], (R)ray.org[2]};
-            R d[3] = {(R)ray.dir[0], (R)ray.dir[1], (R)ray.dir[2]};
+            // Only origin and direction are read before the walk; what the hit record needs besides (the direction the path
+            // continues along, weight, pixel, object) is read after it, from the same cache lines: twenty registers
+            // fewer held across the traversal, which is what decides how many waves a SIMD holds.
+            const RayRec* const rp = rays + ((unsigned long long)shard * shard_cap + i);
+            R o[3] = {(R)rp->org[0], (R)rp->org[1], (R)rp->org[2]};
+            R d[3] = {(R)rp->dir[0], (R)rp->dir[1], (R)rp->dir[2]};
             R dist = R(1e9);
             int io = rtk::trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o, d, dist, st, &ovf_stack, &wc);
             n_secondary++;
+            __asm__ volatile("" ::: "memory");          // (keeps the reads below from being moved up across the walk)
             double t = (double)dist;
             bool go = a.head_quirk ? (t > a.accuracy) : (io >= 0 && t > a.accuracy);   // main.cpp:193,245
-            if (go && a.obj_live) go = a.obj_live[a.head_quirk ? ray.obj : io] != 0;
+            const uint32_t ray_pixel = rp->pixel & (HIT_PIXEL_MASK | RAY_REFRACT);
+            const int32_t ray_obj = rp->obj;
+            if (go && a.obj_live) go = a.obj_live[a.head_quirk ? ray_obj : io] != 0;
             if (go) {
-                rtm::D3 org = {ray.org[0], ray.org[1], ray.org[2]}, dir = {ray.cont[0], ray.cont[1], ray.cont[2]};
-                const bool refract = (ray.pixel & RAY_REFRACT) != 0;
+                rtm::D3 org = {rp->org[0], rp->org[1], rp->org[2]}, dir = {rp->cont[0], rp->cont[1], rp->cont[2]};
+                const bool refract = (ray_pixel & RAY_REFRACT) != 0;
                 rtm::D3 np = rtm::vadd(org, rtm::vmul(dir, refract ? a.accuracy + t : t));   // main.cpp:195, 246
                 next.pos[0] = np.x; next.pos[1] = np.y; next.pos[2] = np.z;
                 next.dir[0] = dir.x; next.dir[1] = dir.y; next.dir[2] = dir.z;
-                next.weight = ray.weight;
-                next.pixel = ray.pixel & ~RAY_REFRACT;
-                next.obj = a.head_quirk ? ray.obj : io;                          // main.cpp:198, 249
+                next.weight = rp->weight;
+                next.pixel = ray_pixel & ~RAY_REFRACT;
+                next.obj = a.head_quirk ? ray_obj : io;                          // main.cpp:198, 249
                 want = true;
             }
         }
