@@ -1511,8 +1511,12 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     rtr::HitRec* qout = (rtr::HitRec*)ctx->hits_b.p;
     for (int level = 1; level <= levels; level++) {
         const int last = level == levels ? 1 : 0;
-        hipLaunchKernelGGL(rtr::shade_kernel, dim3(shade_blocks), dim3(rtk::BLOCK), 0, ctx->stream, sd, a, level, last, qin, (rtr::RayRec*)ctx->rays.p,
-                           (rtg::GatherRec*)ctx->gq.p, shard_cap, gq_cap, ctr);
+        if (ctx->has_glossy)
+            hipLaunchKernelGGL(rtr::shade_kernel<true>, dim3(shade_blocks), dim3(rtk::BLOCK), 0, ctx->stream, sd, a, level, last, qin, (rtr::RayRec*)ctx->rays.p,
+                               (rtg::GatherRec*)ctx->gq.p, shard_cap, gq_cap, ctr);
+        else
+            hipLaunchKernelGGL(rtr::shade_kernel<false>, dim3(shade_blocks), dim3(rtk::BLOCK), 0, ctx->stream, sd, a, level, last, qin, (rtr::RayRec*)ctx->rays.p,
+                               (rtg::GatherRec*)ctx->gq.p, shard_cap, gq_cap, ctr);
         HIP_TRY(hipGetLastError());
         if (!last) {
             hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE, COUNT>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,

@@ -216,6 +216,9 @@ __device__ __forceinline__ void push_rays(RayRec* q, rtq::Counts* cnt, unsigned 
 }
 
 // One recursion level of getColorAt for every queued hit, up to the point where it would call Shoot.
+// GLOSSY: some material of the scene takes the 16-sample loops (main.cpp:177-257); without one the loops are a single
+// pass and the kernel needs far fewer registers.
+template <bool GLOSSY>
 __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a, int level, int last_level, const HitRec* __restrict__ in,
                                                       RayRec* __restrict__ rays, rtg::GatherRec* __restrict__ gq, unsigned long long shard_cap,
                                                       unsigned long long gq_cap, RenderCounters* ctr)
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
                 if (!last_level) {   // children of the last level return black (main.cpp:161): not traced
                     hp = hit_pos; pix = rec.pixel; from = rec.obj;
                     key = rtm::path_key(hit_pos);
-                    n_samp = rtm::glossy_special(special) ? rtm::GLOSSY_SAMPLE : 1;          // main.cpp:177-179
+                    n_samp = GLOSSY && rtm::glossy_special(special) ? rtm::GLOSSY_SAMPLE : 1;          // main.cpp:177-179
                     Rd = rtm::reflect_dir(hit_normal, hit_dir);                            // main.cpp:170
                     Nr = hit_normal;
                     w_refl = special > 1 ? rec.weight * (2 - special) : rec.weight;          // main.cpp:200-203
@@ -322,11 +325,11 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
             }
         }
         // the sample loops: one reflection ray, and one refraction ray where there is one, per sample
-        const int wave_samples = __builtin_amdgcn_readfirstlane((int)rtk_wave_max(n_samp));
+        const int wave_samples = GLOSSY ? __builtin_amdgcn_readfirstlane((int)rtk_wave_max(n_samp)) : (__ballot(n_samp > 0) ? 1 : 0);
         for (int i = 0; i < wave_samples; i++) {
             RayRec next;
             const bool mine = i < n_samp;
-            const bool glossy = n_samp > 1;
+            const bool glossy = GLOSSY && n_samp > 1;
             bool want = mine;
             if (mine) {
                 rtm::D3 dir = Rd;
