@@ -597,6 +597,10 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
     const unsigned long long cap_v = ((unsigned long long)batch * 4 + rtq::SHARDS - 1) / rtq::SHARDS + 16384;
     if ((rc = ctx->hits_a.reserve(cap_s * rtq::SHARDS * sizeof(rte::PhotonOut)))) return rc;
     if ((rc = ctx->hits_b.reserve(cap_v * rtq::SHARDS * sizeof(rte::PhotonOut)))) return rc;
+    // the photons between two bounces: two lists that take turns (the ray and gather queues of the pixel path are idle here)
+    if (bounce < 0 || bounce >= rte::MAX_EMIT_LEVELS) return fail(RT_ERR_LIMIT, "bounce limit %d outside [0,%d)", bounce, rte::MAX_EMIT_LEVELS);
+    if ((rc = ctx->rays.reserve((size_t)batch * sizeof(rte::PhotonState)))) return rc;
+    if ((rc = ctx->gq.reserve((size_t)batch * sizeof(rte::PhotonState)))) return rc;
     rte::ShadeTables sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     rte::EmitCounters* ctr = (rte::EmitCounters*)ctx->counters.p;
     uint64_t rays = 0;
@@ -611,9 +615,14 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
         a.accuracy = accuracy;
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rte::EmitCounters), ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-        hipLaunchKernelGGL((rte::emit_kernel<double>), dim3((unsigned)((a.n_emit + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), lds, ctx->stream,
-                           ctx->v64, sd, a, (rte::PhotonOut*)ctx->hits_a.p, cap_s, (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap);
-        HIP_TRY(hipGetLastError());
+        // one launch per bounce; a later bounce's grid is sized for all photons and the lanes beyond the survivors leave at once
+        rte::PhotonState* lists[2] = {(rte::PhotonState*)ctx->rays.p, (rte::PhotonState*)ctx->gq.p};
+        for (int b = 0; b <= bounce; b++) {
+            hipLaunchKernelGGL((rte::emit_kernel<double>), dim3((unsigned)((a.n_emit + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), lds, ctx->stream,
+                               ctx->v64, sd, a, b, (const rte::PhotonState*)lists[b & 1], lists[(b + 1) & 1], (rte::PhotonOut*)ctx->hits_a.p, cap_s,
+                               (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         rte::EmitCounters hc;
         HIP_TRY(hipMemcpyAsync(&hc, ctr, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));

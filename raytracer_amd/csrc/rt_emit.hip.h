@@ -35,9 +35,19 @@ struct EmitArgs {
     double accuracy;
 };
 
+constexpr int MAX_EMIT_LEVELS = 32;
 struct EmitCounters {
     rtq::Counts surface, volume;
     unsigned long long overflow_stack, overflow_queue, rays, pad[5];
+    unsigned long long walking[MAX_EMIT_LEVELS + 1];    // walking[b]: photons that go into bounce b (b >= 1; bounce 0 takes all)
+};
+
+// A photon between two bounces of its walk.
+struct PhotonState {
+    double org[3], dir[3], light[3];
+    unsigned long long pn;       // photon number: keys its random stream and its records
+    uint32_t draws;              // draws taken from the stream so far
+    uint32_t pad;
 };
 
 struct ShadeTables {
@@ -60,10 +70,13 @@ struct LaneRng {
     }
 };
 
+// One bounce of every photon still walking (main.cpp:396-600), one photon per lane.  Bounce 0 starts the photons at the
+// light; a later bounce takes the survivors of the one before, compacted: walks end at very different lengths, and a wave
+// that carried its photons from the light to their ends ran with a sixth of its lanes on average.
 template <class R>
-__global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> sv, ShadeTables sd, EmitArgs a, PhotonOut* __restrict__ surf,
-                                                             unsigned long long cap_s, PhotonOut* __restrict__ vol, unsigned long long cap_v,
-                                                             EmitCounters* ctr, int cap)
+__global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> sv, ShadeTables sd, EmitArgs a, int bounce, const PhotonState* __restrict__ from,
+                                                             PhotonState* __restrict__ onward, PhotonOut* __restrict__ surf, unsigned long long cap_s,
+                                                             PhotonOut* __restrict__ vol, unsigned long long cap_v, EmitCounters* ctr, int cap)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     LaneStack st = rtk::make_stack<R>(lds, cap);
@@ -71,21 +84,29 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> 
     unsigned long long ovf_queue = 0, n_rays = 0;
     const double PI_REF = 3.1415926;   // main.cpp:24
     const long long local = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    bool alive = local < a.n_emit;
-    const unsigned long long pn = (unsigned long long)(a.first + local);
-    LaneRng rng{(uint32_t)pn ^ a.seed * 0x9E3779B9u, (uint32_t)(pn >> 32) + a.seed, 0u};
-
+    const long long n_here = bounce == 0 ? a.n_emit : (long long)ctr->walking[bounce];
+    bool alive = local < n_here;
+    unsigned long long pn = 0;
     D3 org = {a.light[0], a.light[1], a.light[2]};
     D3 dir = {1, 0, 0};
-    if (alive) {   // main.cpp:702-708: uniform in the unit ball by rejection, then normalised
+    double light[3] = {1.0, 1.0, 1.0};   // white_light, main.cpp:637,685
+    uint32_t draws = 0;
+    if (alive && bounce > 0) {
+        const PhotonState& ps = from[local];
+        org = D3{ps.org[0], ps.org[1], ps.org[2]}; dir = D3{ps.dir[0], ps.dir[1], ps.dir[2]};
+        for (int i = 0; i < 3; i++) light[i] = ps.light[i];
+        pn = ps.pn; draws = ps.draws;
+    } else if (alive) {
+        pn = (unsigned long long)(a.first + local);
+    }
+    LaneRng rng{(uint32_t)pn ^ a.seed * 0x9E3779B9u, (uint32_t)(pn >> 32) + a.seed, draws};
+    if (alive && bounce == 0) {   // main.cpp:702-708: uniform in the unit ball by rejection, then normalised
         double x, y, z;
         do { x = 2 * rng.unit() - 1; y = 2 * rng.unit() - 1; z = 2 * rng.unit() - 1; } while (x * x + y * y + z * z > 1);
         dir = rtm::vnorm(D3{x, y, z});
     }
-    double light[3] = {1.0, 1.0, 1.0};   // white_light, main.cpp:637,685
 
-    for (int bounce = 0; bounce <= a.bounce; bounce++) {      // main.cpp:398: depth > BOUNCE ends the walk
-        if (!__any(alive)) break;
+    {      // (main.cpp:398: depth > BOUNCE ends the walk -- the host launches bounces 0 .. BOUNCE)
         int io = -1;
         double dist = 1e9;
         if (alive) {
@@ -216,6 +237,24 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> 
                     }
                 }
                 rtq::push(vol, &ctr->volume, cap_v, vstore, vrec, &ovf_queue);
+            }
+        }
+    }
+    // the photons that walk on: appended to the next bounce's list, one counter update per wave
+    if (bounce < a.bounce) {
+        const unsigned long long m = __ballot(alive);
+        if (m) {
+            const int leader = __builtin_ctzll(m);
+            unsigned long long base = 0;
+            if ((int)(threadIdx.x & 63) == leader) base = atomicAdd(&ctr->walking[bounce + 1], (unsigned long long)__builtin_popcountll(m));
+            base = ((unsigned long long)(unsigned)__shfl((unsigned)(base >> 32), leader) << 32) | (unsigned)__shfl((unsigned)base, leader);
+            if (alive) {
+                PhotonState ps;
+                ps.org[0] = org.x; ps.org[1] = org.y; ps.org[2] = org.z;
+                ps.dir[0] = dir.x; ps.dir[1] = dir.y; ps.dir[2] = dir.z;
+                for (int i = 0; i < 3; i++) ps.light[i] = light[i];
+                ps.pn = pn; ps.draws = rng.ctr; ps.pad = 0;
+                onward[base + rtq::prefix_rank(m)] = ps;
             }
         }
     }
