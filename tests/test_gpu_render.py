@@ -388,6 +388,53 @@ def test_render_glossy_glass_filling_the_frame(gpu_ctx, monkeypatch):
     assert np.abs(rgb2 - rgb).max() < 1e-9 * max(1.0, np.abs(rgb).max())
 
 
+def _random_scene(api, seed):
+    """Spheres, loose triangles and a plane of random materials (diffuse, mirror, glass, glossy mirror, glossy glass)
+    inside the Cornell box."""
+    r = np.random.default_rng(seed)
+    specials = [0.0, 0.0, 0.6, 1.8, 0.987654, 1.887654]
+    for _ in range(int(r.integers(3, 7))):
+        c = r.uniform(-0.6, 0.6, 3)
+        sp = specials[int(r.integers(0, len(specials)))]
+        api.add_sphere(tuple(c), float(r.uniform(0.12, 0.3)), (float(r.uniform(0.3, 1)), float(r.uniform(0.3, 1)), float(r.uniform(0.3, 1)), sp),
+                       float(r.uniform(1.2, 1.7)))
+    for _ in range(int(r.integers(2, 6))):
+        A = r.uniform(-0.8, 0.8, 3)
+        B, C = A + r.uniform(-0.5, 0.5, 3), A + r.uniform(-0.5, 0.5, 3)
+        sp = specials[int(r.integers(0, 4))]
+        api.add_triangle(tuple(A), tuple(C), tuple(B), (float(r.uniform(0.3, 1)), float(r.uniform(0.3, 1)), float(r.uniform(0.3, 1)), sp), 1.5)
+    api.add_plane((0.0, 1.0, 0.0), -0.95, (0.7, 0.7, 0.7, 0.0))
+    api.add_cornell()
+    api.build_bvh()
+    return api
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_render_random_scenes_match_oracle(gpu_ctx, seed):
+    """Random mixes of the primitive kinds and material classes, anti-aliased, at the default depth: the frame is the
+    restatement's (same counter-based draws for the glossy loops)."""
+    s = _random_scene(rt.Scene(), seed)
+    orc = _random_scene(Oracle(), seed)
+    gpu_ctx.upload(s)
+    s.emit_photons(8000, seed=seed)
+    ph = s.photons_get(0)
+    gpu_ctx.photons_upload(ph)
+    orc.photons_set(np.c_[ph, np.zeros(len(ph))], 0)
+    orc.build_kdtree()
+    w, h, aa = 72, 54, 2
+    p = rt.default_params(width=w, height=h, aadepth=aa, photon_num=8000, photon_use=40, rng_seed=seed)
+    rgb, bgr, st = gpu_ctx.render(rt.look_at(CAM[:3], CAM[3:]), p)
+    orc.params.photon_num = 8000
+    orc.params.photon_use = 40
+    orc.params.counter_rng = 1
+    orc.params.rng_seed = seed
+    ref, nrays = orc.render(w, h, CAM, aadepth=aa, threads=8)
+    a, b = u8(rgb), u8(ref)
+    within = (np.abs(a - b).max(-1) <= 1).mean()
+    print(f"random scene {seed}: within 1 LSB {within:.5f}, max {np.abs(a - b).max()}, rays {st.secondary_rays}, mean level {b.mean():.1f}")
+    assert b.max() > 20 and within >= 0.999
+
+
 @pytest.mark.parametrize("aadepth,dof", [(1, 8), (2, 3)])
 def test_render_depth_of_field(gpu_ctx, aadepth, dof):
     """Depth of field (main.cpp:792-826, DOF_SAMPLE > 1): lens positions from the counter-based stream, the
