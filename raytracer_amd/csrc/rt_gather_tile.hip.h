@@ -283,7 +283,11 @@ __device__ __attribute__((noinline)) int select_leaves(const float* __restrict__
 __device__ __forceinline__ uint32_t* lane_tables() { return reinterpret_cast<uint32_t*>(g_L.key); }   // [row][lane] over the candidates' distances
 
 // 3a: the lane's histogram (see hist_add) of the squared distances from its point to the photons of the list
-__device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, Shell sh, int n_leaf, int n_piv)
+// `radius2` < 3e38 in some lane (`any_radius`): that lane's bound is the search radius itself, which is exclusive
+// (Kdtree.cpp:77,82) -- the bins' last edge lies a rounding error beyond it, so such a lane compares explicitly.
+template <bool any_radius>
+__device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, Shell sh, float radius2,
+                                                    int n_leaf, int n_piv)
 {
     uint32_t* const cell = lane_tables();
     const int lane = lane_id();
@@ -306,10 +310,15 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
         auto bin4 = [&](const Xyz4& c) {
             const D2x4 d = quad_d2(c, qx, qy, qz);
             const f2 at_a = shell_pos(d.a, sh), at_b = shell_pos(d.b, sh);
-            hist_add(mine, unit, shell_bin_of(at_a.x));
-            hist_add(mine, unit, shell_bin_of(at_a.y));
-            hist_add(mine, unit, shell_bin_of(at_b.x));
-            hist_add(mine, unit, shell_bin_of(at_b.y));
+            int b0 = shell_bin_of(at_a.x), b1 = shell_bin_of(at_a.y), b2 = shell_bin_of(at_b.x), b3 = shell_bin_of(at_b.y);
+            if (any_radius) {
+                b0 = d.a.x < radius2 ? b0 : T_BINS - 1; b1 = d.a.y < radius2 ? b1 : T_BINS - 1;
+                b2 = d.b.x < radius2 ? b2 : T_BINS - 1; b3 = d.b.y < radius2 ? b3 : T_BINS - 1;
+            }
+            hist_add(mine, unit, b0);
+            hist_add(mine, unit, b1);
+            hist_add(mine, unit, b2);
+            hist_add(mine, unit, b3);
         };
         Xyz4 c0 = quad_load(0), c1;
         for (int j0 = 0; j0 < n_now; j0 += 8) {
@@ -324,7 +333,8 @@ __device__ __attribute__((noinline)) void pass_hist(const float4* __restrict__ p
 
 // 3b: cell[i][lane] = the i-th squared distance of the lane that falls into its bin `crit` (1 .. T_BINS - 2; < 0: the
 // lane takes no part); returns their number
-__device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, Shell sh, int crit,
+template <bool any_radius>
+__device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ pos, const uint32_t* leaf, float qx, float qy, float qz, Shell sh, float radius2, int crit,
                                                    int n_leaf, int n_piv)
 {
     uint32_t* const cell = lane_tables();
@@ -351,7 +361,10 @@ __device__ __attribute__((noinline)) int pass_crit(const float4* __restrict__ po
             const D2x4 d = quad_d2(c, qx, qy, qz);
             const f2 at_a = shell_pos(d.a, sh), at_b = shell_pos(d.b, sh);
             const f2 t_a = at_a - crit_2, t_b = at_b - crit_2;
-            const uint32_t u0 = __float_as_uint(t_a.x), u1 = __float_as_uint(t_a.y), u2 = __float_as_uint(t_b.x), u3 = __float_as_uint(t_b.y);
+            uint32_t u0 = __float_as_uint(t_a.x), u1 = __float_as_uint(t_a.y), u2 = __float_as_uint(t_b.x), u3 = __float_as_uint(t_b.y);
+            if (any_radius) {      // (what the histogram put into the last bin is not in this one)
+                u0 = d.a.x < radius2 ? u0 : ONE; u1 = d.a.y < radius2 ? u1 : ONE; u2 = d.b.x < radius2 ? u2 : ONE; u3 = d.b.y < radius2 ? u3 : ONE;
+            }
             const uint32_t least = min(min(u0, u1), min(u2, u3));
             if (__ballot(least < ONE)) {           // rare: a few dozen photons per request
                 if (u0 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.x); cnt++; }
@@ -556,11 +569,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             pr[TP_ROUNDS]++; pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_leaf + (n_piv + WAVE - 1) / WAVE;
 
             const Shell sh = shell_of(bound, lower);
+            const float radius2 = act && !(bound < gp.r2) ? gp.r2 : 3.0e38f;      // lanes bounded by the search radius itself
+            const bool any_radius = __ballot(radius2 < 3.0e38f) != 0;
             // ---- 3a. per-lane histogram of the squared distances below the lane's bound
             // leaves that lie inside every request's inner ball count as a whole; the others go photon by photon
             int n_inside;
             const int n_hist = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, act ? lower : 3.0e38f, act ? 3.0e38f : -1.f, n_leaf, &n_inside);
-            TILE_PROF(TP_HIST, pass_hist(pm.pos, g_T.part, qx, qy, qz, sh, n_hist, n_piv));
+            if (any_radius) TILE_PROF(TP_HIST, pass_hist<true>(pm.pos, g_T.part, qx, qy, qz, sh, radius2, n_hist, n_piv));
+            else TILE_PROF(TP_HIST, pass_hist<false>(pm.pos, g_T.part, qx, qy, qz, sh, radius2, n_hist, n_piv));
             pr[TP_N_HIST] += n_hist + (n_piv + WAVE - 1) / WAVE;
             uint32_t* const mine = hist_mine(cell, lane);
             if (act) hist_add(mine, hist_unit(lane) * (uint32_t)n_inside, 0);
@@ -597,7 +613,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             const float shell_lo = crit > 0 ? lower + (float)(crit - 1) / sh.scale : 0.f, shell_hi = crit > 0 ? lower + (float)crit / sh.scale : lower;
             const int n_crit = select_leaves(pm.leaf_box, g_T.leaf, g_T.part, qx, qy, qz, some ? shell_lo * 0.9999f : 3.0e38f, some ? shell_hi * 1.0001f : -1.f, n_leaf,
                                              &n_out);
-            TILE_PROF(TP_CRIT, cnt = pass_crit(pm.pos, g_T.part, qx, qy, qz, sh, some ? crit : -1, n_crit, n_piv));
+            if (any_radius) TILE_PROF(TP_CRIT, cnt = pass_crit<true>(pm.pos, g_T.part, qx, qy, qz, sh, radius2, some ? crit : -1, n_crit, n_piv));
+            else TILE_PROF(TP_CRIT, cnt = pass_crit<false>(pm.pos, g_T.part, qx, qy, qz, sh, radius2, some ? crit : -1, n_crit, n_piv));
             pr[TP_N_CRIT] += n_crit + (n_piv + WAVE - 1) / WAVE;
             const unsigned long long t_rank = ta.prof ? clock64() : 0ull;
             const int max_cnt = (int)wave_max_f((float)cnt);
