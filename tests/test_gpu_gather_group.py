@@ -85,9 +85,9 @@ def test_duplicate_photons(gpu_ctx, water_photons):
     col = np.full(pos.shape, 0.8)
     want, _ = gpu_ctx.knn_estimate(p, pos, nrm, col)
     got = gpu_ctx.knn_estimate_grouped(p, pos, nrm, col)
-    # with 40-fold duplicates the k-th distance is shared by many photons of different power: which of them
-    # belong to the set is arbitrary in both forms, so only the bulk of the estimate agrees
-    assert np.abs(got - want).max() < 0.05 * max(want.max(), 1e-9)
+    # with 40-fold duplicates the k-th distance is shared by many photons: which of them belong to the set is decided by
+    # one rule (position in the photon tree) in the per-request kernel, which is where the group form sends such requests
+    assert np.abs(got - want).max() < 1e-6 * max(want.max(), 1e-9)
 
 
 def test_photon_pairs_a_rounding_error_apart(gpu_ctx, water_photons):
