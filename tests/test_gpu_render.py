@@ -580,8 +580,9 @@ def test_full_size_photon_map_frame(gpu_ctx, monkeypatch):
     monkeypatch.delenv("RT_GATHER_MODE")
     assert st_q.gather_single == st_q.gather_queries == st.gather_queries
     err = np.abs(rgb - rgb_q).max(axis=-1)
-    # (a request whose k-th and (k+1)-th distances are equal floats may keep the other photon)
-    assert (err < 1e-7).mean() >= 0.999 and err.max() < 2e-3 and (bgr != bgr_q).mean() < 1e-3, ((err < 1e-7).mean(), err.max())
+    # (the same sets -- photons at exactly the k-th distance are chosen by one rule -- summed in another order, the grouped
+    # form four float terms at a time)
+    assert (err < 1e-7).mean() >= 0.999 and err.max() < 1e-6 and (bgr != bgr_q).mean() < 1e-5, ((err < 1e-7).mean(), err.max(), (bgr != bgr_q).mean())
     ph = gpu_ctx.photon_map_get(0)
     assert ph.shape == (n_surface, 9)
     orc.photons_set(np.c_[ph, np.zeros(len(ph))])
