@@ -316,20 +316,29 @@ def strong_scaling_glass(rt, ctx, torch, dist, dev, world, rank, ext):
     import time as _time
 
     from raytracer_amd import tiling
-    s = rt.Scene()
-    s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
-    s.add_cornell(); s.build_bvh()
-    ctx.upload(s)
     cam = rt.look_at(CAM[:3], CAM[3:])
     w = 3840
     q = tiling.BAND * world
     h = (2160 + q - 1) // q * q                          # whole bands for every rank: 2160 rows, or 2176 where 8 x ranks does not divide that
     rows = h // world
     p = rt.default_params(width=w, height=h, use_photon_map=0, band_rows=tiling.BAND, n_parts=world, part=rank)
-    part = torch.empty((rows, w, 3), dtype=torch.uint8, device=dev)
-    recv = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
-    st = ctx.render_dev(cam, p, (0, rows), None, part.data_ptr(), stats=True)          # warm-up: queues get allocated here
-    rays = torch.tensor([float(st.primary_rays + st.secondary_rays)], dtype=torch.float64, device=dev)
+    failed, n_rays = None, 0.0
+    try:
+        s = rt.Scene()
+        s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
+        s.add_cornell(); s.build_bvh()
+        ctx.upload(s)
+        part = torch.empty((rows, w, 3), dtype=torch.uint8, device=dev)
+        recv = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
+        st = ctx.render_dev(cam, p, (0, rows), None, part.data_ptr(), stats=True)          # warm-up: queues get allocated here
+        n_rays = float(st.primary_rays + st.secondary_rays)
+    except Exception as e:                               # (a rank that cannot set up must not leave the others waiting in a collective)
+        failed = repr(e)
+    ok = torch.tensor([0.0 if failed else 1.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() < 1:
+        return {"error": failed or "set-up failed on another rank"}
+    rays = torch.tensor([n_rays], dtype=torch.float64, device=dev)
     dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     reps = 5
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
