@@ -386,6 +386,13 @@ def test_render_glossy_glass_filling_the_frame(gpu_ctx, monkeypatch):
     monkeypatch.delenv("RT_SHARD_CAP")
     assert st2.secondary_rays == st.secondary_rays and st2.gather_queries == st.gather_queries
     assert np.abs(rgb2 - rgb).max() < 1e-9 * max(1.0, np.abs(rgb).max())
+    # a frame whose sides are no multiples of the tile: the parts' last columns and rows are ragged
+    pr = rt.default_params(width=50, height=37, photon_num=5000, photon_use=20, rng_seed=99)
+    whole, _, st3 = gpu_ctx.render(cam, pr)
+    monkeypatch.setenv("RT_SHARD_CAP", "40000")
+    parts, _, st4 = gpu_ctx.render(cam, pr)
+    monkeypatch.delenv("RT_SHARD_CAP")
+    assert st4.secondary_rays == st3.secondary_rays > 2000 * 50 * 37 and np.abs(parts - whole).max() < 1e-9 * max(1.0, np.abs(whole).max())
 
 
 def _random_scene(api, seed):
