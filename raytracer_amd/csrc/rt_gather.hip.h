@@ -792,7 +792,9 @@ __device__ __forceinline__ double unit_random(uint32_t a, uint32_t b, uint32_t s
 constexpr uint32_t REDO_EMPTY = 0xFFFFFFFFu;    // a list entry nobody has written yet (the list is all REDO_EMPTY between launches)
 
 // the estimate of one queued request, added to its pixel (one wave)
-__device__ __forceinline__ void answer_request(const PhotonMapView& pm, const PhotonMapView& vm, const GatherRec& r, const GatherParams& gp, Neighbour& nb, double* __restrict__ acc)
+// (nb / nbv: what the wave's previous search in the surface / volume map found, see Neighbour)
+__device__ __forceinline__ void answer_request(const PhotonMapView& pm, const PhotonMapView& vm, const GatherRec& r, const GatherParams& gp, Neighbour& nb, Neighbour& nbv,
+                                               double* __restrict__ acc)
 {
     const int lane = lane_id();
     const Prof pf{nullptr};
@@ -805,7 +807,7 @@ __device__ __forceinline__ void answer_request(const PhotonMapView& pm, const Ph
         const float hp[3] = {(float)r.pos[0], (float)r.pos[1], (float)r.pos[2]};
         double sss[3] = {0, 0, 0};
         __builtin_amdgcn_wave_barrier();
-        int vc = knn_collect(vm, hp[0], hp[1], hp[2], gp.k, gp.r2, gp.front_cap, pf);
+        int vc = knn_collect(vm, hp[0], hp[1], hp[2], gp.k, gp.r2, gp.front_cap, pf, &nbv);
         __builtin_amdgcn_wave_barrier();
         volume_step(vm, vc, hp, r.color, 1.0, gp.photon_num, sss);
         if (r.flags & GATHER_MARCH) {
@@ -813,7 +815,7 @@ __device__ __forceinline__ void answer_request(const PhotonMapView& pm, const Ph
             double e_pass = 2.71828;
             for (int pass = 1; pass < 3; pass++) {
                 __builtin_amdgcn_wave_barrier();
-                vc = knn_collect(vm, (float)px, (float)py, (float)pz, gp.k, gp.r2, gp.front_cap, pf);
+                vc = knn_collect(vm, (float)px, (float)py, (float)pz, gp.k, gp.r2, gp.front_cap, pf, &nbv);
                 __builtin_amdgcn_wave_barrier();
                 volume_step(vm, vc, hp, r.color, e_pass, gp.photon_num, sss);
                 // the stream is keyed by what identifies the request whatever the launch: pixel, hit point, pass
@@ -844,7 +846,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const unsigned long long n_all = *n_list;
     const uint32_t n = n_all > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)n_all;
     uint32_t q_end = 0;
-    Neighbour nb{0.f, 0.f, 0.f, -1.f};
+    Neighbour nb{0.f, 0.f, 0.f, -1.f}, nbv{0.f, 0.f, 0.f, -1.f};
     while (true) {
         uint32_t left = n > q_end ? n - q_end : 0;
         uint32_t want = left / (4u * gridDim.x);
@@ -858,7 +860,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             const uint32_t slot = list[q];
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) list[q] = REDO_EMPTY;
-            answer_request(pm, vm, recs[slot], gp, nb, acc);
+            answer_request(pm, vm, recs[slot], gp, nb, nbv, acc);
         }
     }
 }
@@ -877,7 +879,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
     const int lane = lane_id();
     const unsigned long long n_windows = rtq::map_units(cnt, shard_cap, WAVE).total;
     if (__hip_atomic_load(windows_done + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < tile_waves) return;
-    Neighbour nb{0.f, 0.f, 0.f, -1.f};
+    Neighbour nb{0.f, 0.f, 0.f, -1.f}, nbv{0.f, 0.f, 0.f, -1.f};
     while (true) {
         unsigned long long q0 = 0;
         if (lane == 0) q0 = atomicAdd(next, 1ull);
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         if (slot == REDO_EMPTY) break;
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) list[q0] = REDO_EMPTY;
-        answer_request(pm, vm, recs[slot], gp, nb, acc);
+        answer_request(pm, vm, recs[slot], gp, nb, nbv, acc);
     }
 }
 
