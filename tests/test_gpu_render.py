@@ -395,6 +395,37 @@ def test_render_glossy_glass_filling_the_frame(gpu_ctx, monkeypatch):
     assert st4.secondary_rays == st3.secondary_rays > 2000 * 50 * 37 and np.abs(parts - whole).max() < 1e-9 * max(1.0, np.abs(whole).max())
 
 
+@pytest.mark.parametrize("depth", [6, 8])
+def test_render_deeper_than_the_default(gpu_ctx, monkeypatch, depth):
+    """TRACING_DEPTH above the reference's 4: more levels than the queues are sized for in the worst case, so they are
+    a budget and a block of rows that outgrows it is split and rendered again.  The frame is the oracle's at the same
+    depth, and the same for small queues."""
+    rgbs, ior, off = (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0)
+    s = build_scene(rt.Scene(), "teapot_normal.obj", rgbs, ior, off)
+    orc = build_scene(Oracle(), "teapot_normal.obj", rgbs, ior, off)
+    gpu_ctx.upload(s)
+    s.emit_photons(20000, seed=5)
+    ph = s.photons_get(0)
+    gpu_ctx.photons_upload(ph)
+    orc.photons_set(np.c_[ph, np.zeros(len(ph))], 0)
+    orc.build_kdtree()
+    w, h = 96, 72
+    p = rt.default_params(width=w, height=h, photon_num=20000, photon_use=50, tracing_depth=depth)
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    rgb, _, st = gpu_ctx.render(cam, p)
+    orc.params.photon_num = 20000
+    orc.params.photon_use = 50
+    orc.params.tracing_depth = depth
+    ref, _ = orc.render(w, h, CAM, threads=8)
+    assert_image_close(rgb, ref, what=f"glass teapot at depth {depth}")
+    shallow, _, st4 = gpu_ctx.render(cam, rt.default_params(width=w, height=h, photon_num=20000, photon_use=50))
+    assert st.secondary_rays > st4.secondary_rays and np.abs(rgb - shallow).max() > 1e-3       # the extra levels are there
+    monkeypatch.setenv("RT_SHARD_CAP", "1024")
+    small, _, st_small = gpu_ctx.render(cam, p)
+    monkeypatch.delenv("RT_SHARD_CAP")
+    assert st_small.secondary_rays == st.secondary_rays and np.abs(small - rgb).max() < 1e-9
+
+
 def _random_scene(api, seed):
     """Spheres, loose triangles and a plane of random materials (diffuse, mirror, glass, glossy mirror, glossy glass)
     inside the Cornell box."""
