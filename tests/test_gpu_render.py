@@ -426,6 +426,23 @@ def test_render_deeper_than_the_default(gpu_ctx, monkeypatch, depth):
     assert st_small.secondary_rays == st.secondary_rays and np.abs(small - rgb).max() < 1e-9
 
 
+@pytest.mark.parametrize("head_quirk", [0, 1])
+def test_no_photon_map_traces_the_same_rays(gpu_ctx, head_quirk):
+    """Without a photon map the frame is black (the reference has no direct light) and hits that spawn no rays are not
+    queued for shading; the rays traced are exactly those of the frame with a photon map, in both recursion modes."""
+    s = _glossy_scene(rt.Scene())
+    gpu_ctx.upload(s)
+    s.emit_photons(5000, seed=3)
+    gpu_ctx.photons_upload(s.photons_get(0))
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    kw = dict(width=160, height=120, photon_num=5000, photon_use=20, rng_seed=5, head_quirk=head_quirk)
+    lit, _, st1 = gpu_ctx.render(cam, rt.default_params(use_photon_map=1, **kw))
+    dark, bgr, st0 = gpu_ctx.render(cam, rt.default_params(use_photon_map=0, **kw))
+    assert st0.secondary_rays == st1.secondary_rays > 50000 and st0.primary_rays == st1.primary_rays
+    assert st0.gather_queries == 0 and st1.gather_queries > 0
+    assert (dark == 0).all() and (bgr == 0).all() and lit.max() > 0.05
+
+
 def _random_scene(api, seed):
     """Spheres, loose triangles and a plane of random materials (diffuse, mirror, glass, glossy mirror, glossy glass)
     inside the Cornell box."""
