@@ -97,3 +97,26 @@ def test_device_map_errors(gpu_ctx):
     gpu_ctx.photons_upload(_photons(100, "box", 0))
     with pytest.raises(rt.RtError):
         gpu_ctx.photon_map_get(0)            # a host-built map keeps no list on the device
+
+
+def test_emission_bounce_limits(gpu_ctx):
+    """BOUNCE (main.cpp:25) from 0 (the first hit only) up: one launch per bounce with the survivors handed on; both
+    device routes store the same photons, a longer walk stores more of them, and the serial host walk of the same
+    limit stores about as many."""
+    n = 60000
+    stored = []
+    for bounce in (0, 1, 7):
+        # (a fresh scene per limit: both emissions append to the scene's lists, as main.cpp:89 does)
+        s = build_scene(rt.Scene(), "teapot_normal.obj", (0.9, 0.9, 0.9, 0.6), 1.3, (0, -0.7, 0))      # a mirror teapot in the box
+        gpu_ctx.upload(s)
+        s.emit_photons_gpu(gpu_ctx, n, seed=3, bounce=bounce)
+        lst = s.photons_get(0)
+        (ns, nv), _ = gpu_ctx.emit_photon_maps(n, seed=3, bounce=bounce)
+        assert ns == len(lst) and nv == 0 and np.array_equal(gpu_ctx.photon_map_get(0), lst)
+        s.emit_photons(n, seed=3, bounce=bounce)
+        host = s.photon_count(0) - ns
+        assert abs(ns - host) < 0.02 * host + 50, (bounce, ns, host)
+        stored.append(ns)
+    assert 0 < stored[0] <= n and stored[0] < stored[1] < stored[2]
+    with pytest.raises(rt.RtError):
+        gpu_ctx.emit_photon_maps(n, seed=3, bounce=8)        # (a photon's records are keyed photon * 64 + bounce * 8 + slot)
