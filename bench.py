@@ -292,6 +292,8 @@ def main():
             "value": round(alt_rays / (alt_ms * 1e-3) / 1e6, 2),
             "ms_per_step": round(alt_ms, 4),
             "kernel_ms_avg": round(alt_dev_ms, 4),
+            "note": ("hit ids of the f32 instantiation differ from the reference's (f64) on the fraction of pixels given in "
+                     "parity.f32_id_mismatch_fraction (silhouettes); they equal the single-precision restatement's exactly"),
         },
         "cpu_baseline": cpu,
         "parity": parity,
