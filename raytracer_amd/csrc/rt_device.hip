@@ -9,6 +9,8 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rt_amd.h"
@@ -123,6 +125,7 @@ struct rt_context {
     rtf::SceneView<float> v32{};
     int depth = 0;
     int n_nodes = 0;
+    int n_prims = 0;          // primitive records in the tree's leaves
     int n_objects = 0;
     bool has_scene = false;
     bool has_glossy = false;  // some material takes the 16-sample loops of main.cpp:177-257
@@ -192,6 +195,21 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
     hipLaunchKernelGGL((rtk::trace_batch_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), (long long)n, d_org,
                        d_dir, d_dist, d_ids, (rtk::TraceCounters*)ctx->counters.p, cap);
     HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+// A launch with more than 64 KiB of dynamic LDS has to be allowed per kernel and device first.  The call is made once per
+// (device, kernel, size reached): between the launches of a frame it would leave the GPU waiting for the host.
+int allow_dynamic_lds(const rt_context* ctx, const void* kernel, size_t bytes)
+{
+    if (bytes <= 64 * 1024) return RT_OK;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> allowed;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = allowed[{ctx->device, kernel}];
+    if (have >= bytes) return RT_OK;
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    have = bytes;
     return RT_OK;
 }
 
@@ -945,6 +963,7 @@ int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
     ctx->v64.tri_only = ctx->v32.tri_only = tri_only ? 1 : 0;
     ctx->depth = b.depth;
     ctx->n_nodes = (int)b.nodes.size();
+    ctx->n_prims = (int)b.prims.size();
     ctx->n_objects = (int)s.objects.size();
     ctx->has_scene = true;
     return RT_OK;
@@ -1071,6 +1090,7 @@ int rt_scene_upload_lbvh(rt_context* ctx, const rt_scene* scene, double* build_m
     ctx->v64.tri_only = ctx->v32.tri_only = tri_only ? 1 : 0;
     ctx->depth = depth;
     ctx->n_nodes = (int)n_nodes;
+    ctx->n_prims = (int)n;
     ctx->n_objects = (int)s.objects.size();
     ctx->has_scene = true;
     return RT_OK;
@@ -1516,6 +1536,20 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     const int trace_blocks_cu = std::max(1, std::min<int>((int)(160 * 1024 / std::max<size_t>(g.lds, 1)), 16 / wpb));
     const int trace_blocks = ctx->num_cus * trace_blocks_cu;
     const int shade_blocks = ctx->num_cus * 4;
+    // Small scenes: the queue tracer keeps nodes AND primitive records in LDS, one block per CU with as many waves as the
+    // stacks leave room for (a window's 64 rays meet 64 different triangles; LDS returns them four times as fast as L1).
+    int resident_waves = 0;
+    size_t resident_lds = 0;
+    if (MODE == rtk::TRAV_NODES && !getenv("RT_NO_SCENE_LDS")) {
+        const size_t image = rtk::node_lds_bytes<R>((size_t)ctx->n_nodes) + rtk::prim_lds_bytes<R>((size_t)ctx->n_prims);
+        const size_t per_wave = rtk::stack_lds_bytes(cap, sizeof(float), 1);
+        if (image + 8 * per_wave <= 160 * 1024) {
+            // (at most 14: a block of 16 waves measured a third slower than one of 14 -- the float glass frame 1.39 ms against 1.03)
+            resident_waves = (int)std::min<size_t>(14, (160 * 1024 - image) / per_wave);
+            if (const char* e = getenv("RT_SCENE_WAVES")) resident_waves = std::max(1, std::min(resident_waves, atoi(e)));      // tuning aid
+            resident_lds = image + resident_waves * per_wave;
+        }
+    }
     rtr::HitRec* qin = (rtr::HitRec*)ctx->hits_a.p;
     rtr::HitRec* qout = (rtr::HitRec*)ctx->hits_b.p;
     for (int level = 1; level <= levels; level++) {
@@ -1528,8 +1562,13 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
                                (rtg::GatherRec*)ctx->gq.p, shard_cap, gq_cap, ctr);
         HIP_TRY(hipGetLastError());
         if (!last) {
-            hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE, COUNT>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
-                               (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes);
+            if (MODE == rtk::TRAV_NODES && resident_waves > 0) {
+                if (int rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::trace_queue_kernel<R, TRI_ONLY, rtk::TRAV_SCENE, COUNT>), resident_lds)) return rc_lds;
+                hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, rtk::TRAV_SCENE, COUNT>), dim3(ctx->num_cus), dim3(resident_waves * 64), resident_lds, ctx->stream,
+                                   view<R>(ctx), a, level, (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes, ctx->n_prims);
+            } else
+                hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE, COUNT>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
+                                   (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes, ctx->n_prims);
             HIP_TRY(hipGetLastError());
         }
         std::swap(qin, qout);

@@ -25,12 +25,21 @@ constexpr int MAX_BLOCK = 768;   // register budget of the traversal kernels: co
 //                 child's box is tested again when it is popped -- the reference's own entry
 //                 re-test (BVH.cpp:132) -- so a third of the LDS per wave buys three times the
 //                 resident waves where the stack depth limits occupancy
-constexpr int TRAV_PLAIN = 0, TRAV_NODES = 1, TRAV_RETEST = 2;
+//   TRAV_SCENE    small scenes, persistent kernels: node array AND primitive records copied into the block's
+//                 LDS once (one block per CU); rays that diverge fetch a different primitive record per lane,
+//                 which LDS serves at 256 B per clock where the L1's data return path serves 64
+constexpr int TRAV_PLAIN = 0, TRAV_NODES = 1, TRAV_RETEST = 2, TRAV_SCENE = 3;
+constexpr bool nodes_in_lds(int mode) { return mode == TRAV_NODES || mode == TRAV_SCENE; }
+
+// 16 bytes read from LDS by address space, so the read is a ds_read_b128 whatever the compiler can prove about the pointer
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) u4v lds_u4;
 
 struct LaneStack {
     uint32_t* ref;   // [depth][64] for this wave
     void* t0;        // [depth][64] of R
-    const uint4* lds_nodes;   // node image in LDS (NLDS kernels), else unused
+    const uint4* lds_nodes;   // node image in LDS (TRAV_NODES / TRAV_SCENE kernels), else unused
+    const uint4* lds_prims;   // primitive records in LDS (TRAV_SCENE kernels), else unused
     int lane;
     int cap;
 };
@@ -57,14 +66,34 @@ __device__ __forceinline__ void stage_nodes(uint4* dst, const rtf::Node<R>* node
     __syncthreads();
 }
 
+// Primitive records staged in LDS as they are (float 48 B, double 80 B: 3 / 5 slots of 16 bytes, an odd number, so
+// lanes reading different records spread over the 16 slots of a bank row).
+template <class R>
+__host__ __device__ inline size_t prim_lds_bytes(size_t n_prims) { return n_prims * sizeof(rtf::Prim<R>); }
+
+template <class R>
+__device__ __forceinline__ void stage_prims(uint4* dst, const rtf::Prim<R>* prims, int n_prims)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(prims);
+    const int n16 = n_prims * (int)(sizeof(rtf::Prim<R>) / 16);
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
 template <class R, int MODE>
 __device__ __forceinline__ rtf::Node<R> fetch_node(const rtf::Node<R>* __restrict__ nodes, const uint4* lds_nodes, uint32_t idx)
 {
     constexpr int CH = NodeLds<R>::CHUNKS, ST = NodeLds<R>::STRIDE;
     uint4 v[sizeof(rtf::Node<R>) / 16];
-    const uint4* src = MODE == TRAV_NODES ? lds_nodes + (size_t)idx * ST : reinterpret_cast<const uint4*>(nodes + idx);
+    if (nodes_in_lds(MODE)) {
+        const lds_u4* src = (const lds_u4*)(lds_nodes + (size_t)idx * ST);
 #pragma unroll
-    for (int i = 0; i < CH; i++) v[i] = src[i];
+        for (int i = 0; i < CH; i++) { const u4v t = src[i]; v[i] = uint4{t.x, t.y, t.z, t.w}; }
+    } else {
+        const uint4* src = reinterpret_cast<const uint4*>(nodes + idx);
+#pragma unroll
+        for (int i = 0; i < CH; i++) v[i] = src[i];
+    }
     rtf::Node<R> out;
     __builtin_memcpy(&out, v, CH * 16);
     return out;
@@ -77,15 +106,21 @@ template <> __device__ __forceinline__ bool rt_finite<double>(double v) { return
 struct WorkCount { unsigned long long inner = 0, prims = 0; };
 
 // whole primitive record in 16-byte pieces issued back to back (one round trip instead of one per field)
-template <class R>
+template <class R, bool LDS = false>
 __device__ __forceinline__ rtf::Prim<R> load_prim(const rtf::Prim<R>* p)
 {
     constexpr int N = sizeof(rtf::Prim<R>) / 16;
     static_assert(sizeof(rtf::Prim<R>) % 16 == 0, "primitive record is a multiple of 16 bytes");
     uint4 v[N];
-    const uint4* src = reinterpret_cast<const uint4*>(p);
+    if (LDS) {
+        const lds_u4* src = (const lds_u4*)p;
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] = src[i];
+        for (int i = 0; i < N; i++) { const u4v t = src[i]; v[i] = uint4{t.x, t.y, t.z, t.w}; }
+    } else {
+        const uint4* src = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+        for (int i = 0; i < N; i++) v[i] = src[i];
+    }
     rtf::Prim<R> out;
     __builtin_memcpy(&out, v, sizeof(out));
     return out;
@@ -103,7 +138,7 @@ __device__ __forceinline__ void test_prim(const rtf::Prim<R>& p, const R* o, con
 // Leaf: test every primitive in leaf order, accept iff t >= 0 && t < dist (BVH.cpp:135-149).
 // The next record is fetched while the current one is tested; two register sets take turns so that
 // no record is ever copied from one set to the other.
-template <class R, bool COUNT, bool TRI_ONLY>
+template <class R, bool COUNT, bool TRI_ONLY, bool LDS = false>
 __device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims, uint32_t leaf, const R* o, const R* d, R& dist, int& hit,
                                           WorkCount* wc)
 {
@@ -114,12 +149,12 @@ __device__ __forceinline__ void test_leaf(const rtf::Prim<R>* __restrict__ prims
     // the fetches are unconditional (index clamped to the last record) so that they stay in flight
     // across the test instead of being waited for at the join of a divergent branch
     const uint32_t last = cnt - 1;
-    rtf::Prim<R> even = load_prim<R>(p), odd;
+    rtf::Prim<R> even = load_prim<R, LDS>(p), odd;
     for (uint32_t k = 0;; k += 2) {
-        odd = load_prim<R>(p + (k + 1 < last ? k + 1 : last));
+        odd = load_prim<R, LDS>(p + (k + 1 < last ? k + 1 : last));
         test_prim<R, TRI_ONLY>(even, o, d, dist, hit);
         if (k + 1 > last) break;
-        even = load_prim<R>(p + (k + 2 < last ? k + 2 : last));
+        even = load_prim<R, LDS>(p + (k + 2 < last ? k + 2 : last));
         test_prim<R, TRI_ONLY>(odd, o, d, dist, hit);
         if (k + 2 > last) break;
     }
@@ -159,6 +194,8 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
     uint32_t* s_ref = st.ref;
     float* s_t0 = (float*)st.t0;
     const int lane = st.lane;
+    constexpr bool PRIMS_LDS = MODE == TRAV_SCENE;
+    const rtf::Prim<R>* const prims = PRIMS_LDS ? reinterpret_cast<const rtf::Prim<R>*>(st.lds_prims) : sv.prims;
 
     if (sv.root_ref != rtf::NO_NODE) {
         R inv[3] = {R(1) / d[0], R(1) / d[1], R(1) / d[2]};
@@ -195,7 +232,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                         if (h0) { cur = c0; continue; }
                         if (h1) { cur = c1; continue; }
                     } else {
-                        test_leaf<R, COUNT, TRI_ONLY>(sv.prims, cur, o, d, dist, hit, wc);
+                        test_leaf<R, COUNT, TRI_ONLY, PRIMS_LDS>(prims, cur, o, d, dist, hit, wc);
                         if (any_hit && hit >= 0) break;
                     }
                     bool found = false;
@@ -230,7 +267,7 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
                     bool direct = false;
                     if (have) {
                         if (cur & rtf::LEAF_BIT) {
-                            test_leaf<R, COUNT, TRI_ONLY>(sv.prims, cur, o, d, dist, hit, wc);
+                            test_leaf<R, COUNT, TRI_ONLY, PRIMS_LDS>(prims, cur, o, d, dist, hit, wc);
                             if (any_hit && hit >= 0) break;
                         } else {
                             const rtf::Node<R>& nd = sv.nodes[cur];
@@ -272,15 +309,17 @@ __device__ int trace_ray(const rtf::SceneView<R>& sv, const R* o, const R* d, R&
     return hit;
 }
 
-// LDS layout of a block: [node image (node_bytes, may be 0)] [refs: waves x cap x 64 x 4 B] [t0: waves x cap x 64 x 4 B]
+// LDS layout of a block: [node image (node_bytes, may be 0)] [primitive records (prim_bytes, may be 0)]
+// [refs: waves x cap x 64 x 4 B] [t0: waves x cap x 64 x 4 B]
 template <class R>
-__device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, size_t node_bytes = 0)
+__device__ __forceinline__ LaneStack make_stack(unsigned char* lds, int cap, size_t node_bytes = 0, size_t prim_bytes = 0)
 {
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int waves = blockDim.x >> 6;
     LaneStack st;
     st.lds_nodes = reinterpret_cast<const uint4*>(lds);
-    unsigned char* base = lds + node_bytes;
+    st.lds_prims = reinterpret_cast<const uint4*>(lds + node_bytes);
+    unsigned char* base = lds + node_bytes + prim_bytes;
     st.ref = (uint32_t*)base + (size_t)wave * cap * WAVE;
     st.t0 = (void*)((float*)(base + (size_t)waves * cap * WAVE * sizeof(uint32_t)) + (size_t)wave * cap * WAVE);
     st.lane = lane;

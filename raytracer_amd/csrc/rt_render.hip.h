@@ -53,11 +53,14 @@ constexpr uint32_t RAY_REFRACT = 0x80000000u;
 // gather requests it queues then form one group.  The first record of a window carries the number of
 // hits in bits 25..31 of `pixel` (a pixel index stays below 2^25: a call handles at most ~4M camera rays).
 constexpr uint32_t HIT_PIXEL_MASK = (1u << 25) - 1u;
-__device__ __forceinline__ void push_hits(HitRec* q, rtq::Counts* cnt, unsigned long long shard_cap, bool want, HitRec& rec, unsigned long long* overflow)
+// (`spread`: what picks the shard.  A producer whose waves take work as they become free passes the number of the unit
+// it works on, so the shards fill evenly whichever waves did the work.)
+__device__ __forceinline__ void push_hits(HitRec* q, rtq::Counts* cnt, unsigned long long shard_cap, bool want, HitRec& rec, unsigned long long* overflow,
+                                          unsigned spread = rtq::wave_index())
 {
     unsigned long long m = __ballot(want);
     if (m == 0) return;
-    const unsigned shard = rtq::wave_index() & (rtq::SHARDS - 1);
+    const unsigned shard = spread & (rtq::SHARDS - 1);
     const int leader = __builtin_ctzll(m);
     unsigned long long base = 0;
     if ((int)rtq::lane_id() == leader) {
@@ -376,14 +379,16 @@ __global__ __launch_bounds__(BLOCK) void shade_kernel(ShadeData sd, RenderArgs a
 // (The draw loop around the traversal costs this kernel about 45 registers.  It is held to 128 -- four waves per SIMD --
 // which the compiler reaches without spilling once the ray record is read in two parts, see below.)
 template <class R, bool TRI_ONLY, int MODE, bool COUNT = false>
-__global__ __launch_bounds__(rtk::MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(4))) void trace_queue_kernel(rtf::SceneView<R> sv, RenderArgs a, int level, const RayRec* __restrict__ rays,
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(MODE == rtk::TRAV_SCENE && sizeof(R) == 8 ? 3 : 4))) void trace_queue_kernel(rtf::SceneView<R> sv, RenderArgs a, int level, const RayRec* __restrict__ rays,
                                                                     HitRec* __restrict__ out, unsigned long long shard_cap, RenderCounters* ctr,
-                                                                    int cap, int n_nodes)
+                                                                    int cap, int n_nodes, int n_prims)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    const size_t node_bytes = MODE == rtk::TRAV_NODES ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
-    if (MODE == rtk::TRAV_NODES) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
-    LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
+    const size_t node_bytes = rtk::nodes_in_lds(MODE) ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
+    const size_t prim_bytes = MODE == rtk::TRAV_SCENE ? rtk::prim_lds_bytes<R>((size_t)n_prims) : 0;
+    if (MODE == rtk::TRAV_SCENE) rtk::stage_prims<R>(reinterpret_cast<uint4*>(lds + node_bytes), sv.prims, n_prims);
+    if (rtk::nodes_in_lds(MODE)) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes, prim_bytes);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0, n_secondary = 0;
     rtk::WorkCount wc;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) __attribute__((amdgpu_waves_per_eu(
                 want = true;
             }
         }
-        push_hits(out, &ctr->hits[level + 1], shard_cap, want, next, &ovf_queue);
+        push_hits(out, &ctr->hits[level + 1], shard_cap, want, next, &ovf_queue, chunk);
     }
     if (ovf_stack) { atomicMax(&ctr->overflow_stack, 1ull); rtk::latch_overflow(ctr, 0); }
     if (ovf_queue) { atomicMax(&ctr->overflow_queue, 1ull); rtk::latch_overflow(ctr, 1); }
