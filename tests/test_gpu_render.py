@@ -443,6 +443,34 @@ def test_no_photon_map_traces_the_same_rays(gpu_ctx, head_quirk):
     assert (dark == 0).all() and (bgr == 0).all() and lit.max() > 0.05
 
 
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_queue_tracer_scene_in_lds_same_frame(gpu_ctx, monkeypatch, precision, mixed):
+    """Small scenes are traced from LDS by the queue tracer (nodes and primitive records staged once per block), larger
+    ones through L1: the same walk on the same records, so switching the staging off changes nothing -- the same rays
+    and the same frame up to the order of the per-pixel sums.  Triangles only and mixed primitives (the two
+    instantiations of the leaf test), both precisions."""
+    if mixed:
+        s = _random_scene(rt.Scene(), 21)
+    else:
+        s = rt.Scene()
+        s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
+        s.add_cornell()
+        s.build_bvh()
+    gpu_ctx.upload(s)
+    s.emit_photons(4000, seed=9)
+    gpu_ctx.photons_upload(s.photons_get(0))
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    p = rt.default_params(width=320, height=180, photon_num=4000, photon_use=30, rng_seed=4,
+                          precision=rt.RT_F64 if precision == "f64" else rt.RT_F32)
+    lds, _, st_lds = gpu_ctx.render(cam, p)
+    monkeypatch.setenv("RT_NO_SCENE_LDS", "1")
+    l1, _, st_l1 = gpu_ctx.render(cam, p)
+    monkeypatch.delenv("RT_NO_SCENE_LDS")
+    assert st_lds.secondary_rays == st_l1.secondary_rays > 10000 and st_lds.gather_queries == st_l1.gather_queries
+    assert lds.max() > 0.05 and np.abs(lds - l1).max() < 1e-9
+
+
 def _random_scene(api, seed):
     """Spheres, loose triangles and a plane of random materials (diffuse, mirror, glass, glossy mirror, glossy glass)
     inside the Cornell box."""
