@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the wider configurations reported beside the headline")
+    ap.add_argument("--no-c5", action="store_true", help="skip the 10 M-triangle configuration among them (its host-side scene set-up takes most of a minute)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -154,11 +155,9 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(rays.item()), float(tt.item()), e0.elapsed_time(e1) / steps
 
-    rays_per_step, elapsed, head_dev_ms = timed(params, args.steps, args.warmup)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = rays_per_step / (ms_per_step * 1e-3) / 1e6
-
-    # ---- the other instantiation, same protocol (reported beside the headline, never as `value`)
+    # ---- the other instantiation, same protocol (reported beside the headline, never as `value`).  It runs first, and
+    # so do the instrumented launches: a GPU that has been idle raises its clocks over some tens of milliseconds of work,
+    # and the order puts that rise into these runs instead of into a short headline run (20 steps are 6 ms).
     alt_prec = rt.RT_F32 if prec == rt.RT_F64 else rt.RT_F64
     alt_rays, alt_elapsed, alt_dev_ms = timed(make_params(alt_prec), args.steps, min(args.warmup, 2))
     alt_ms = alt_elapsed / args.steps * 1e3
@@ -166,6 +165,11 @@ def main():
     # ---- algorithmic work of one launch, from the instrumented kernel (untimed)
     st_work_plain = ctx.trace_primary_dev(cam, params, (0, part_rows), buf.data_ptr(), None, None, stats=True)
     st_work = ctx.trace_primary_dev(cam, make_params(prec, count_work=1), (0, part_rows), buf.data_ptr(), None, None, stats=True)
+
+    # ---- the headline: W untimed steps, then K timed ones
+    rays_per_step, elapsed, head_dev_ms = timed(params, args.steps, args.warmup)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = rays_per_step / (ms_per_step * 1e-3) / 1e6
     node_b, prim_b = (128, 80) if prec == rt.RT_F64 else (64, 48)
     alg_bytes = st_work.inner_visits * node_b + st_work.prim_tests * prim_b
     rank_rays = st_work.primary_rays + st_work.shadow_rays
@@ -239,7 +243,7 @@ def main():
     extras = None
     if world == 1 and not args.no_extras:
         try:
-            extras = other_configs(rt, ctx, torch, dev)
+            extras = other_configs(rt, ctx, torch, dev, skip_c5=args.no_c5)
         except Exception as e:     # never lose the headline over them
             extras = {"error": repr(e)}
 
@@ -359,11 +363,12 @@ def strong_scaling_glass(rt, ctx, torch, dist, dev, world, rank, ext):
             "Mrays_per_s": round(float(rays.item()) / float(dt.item()) / 1e6, 1), "gather_bytes_per_frame": int(3 * w * h)}
 
 
-def other_configs(rt, ctx, torch, dev):
+def other_configs(rt, ctx, torch, dev, skip_c5=False):
     """The wider configurations on the same GPU, reported beside the headline (never as `value`): the full
-    pixel path with the bounce queue (glass teapot, 3840x2160, depth 4) and with the photon gather (water
-    surface, 1 M photons emitted and both kd-trees built on the device, k = 1000, 1920x1080).  Device time of
-    the whole call from HIP events on the library's stream, best of 3."""
+    pixel path with the bounce queue (glass teapot, 3840x2160, depth 4), with the photon gather (water
+    surface, 1 M photons emitted and both kd-trees built on the device, k = 1000, 1920x1080) and on the
+    10 M-triangle scene at 7680x4320 with 16 samples per pixel.  Device time of the whole call from HIP events
+    on the library's stream, best of 3."""
     cam = rt.look_at(CAM[:3], CAM[3:])
     out = {}
 
@@ -420,7 +425,51 @@ def other_configs(rt, ctx, torch, dev):
         "kernels": "gather_tile_kernel + gather_kernel", "kernels_ms": round(gather_ms, 3), "flop_per_query": k * 38, "bytes_per_query": k * 36,
         "hbm_priced": {"GBps": round(gbytes / (gather_ms * 1e-3) / 1e9, 1), "ratio_to_hbm_peak": round(gbytes / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                        "note": "the 45 MB photon map stays in the Infinity Cache"}}
+    if not skip_c5:
+        out["instanced_teapots_10M_triangles_7680x4320_16spp"] = config5(rt, ctx, torch, dev)
     return out
+
+
+def config5(rt, ctx, torch, dev, n_side=100):
+    """BASELINE's fifth configuration on one GPU: 10 000 copies of the teapot mesh (9.92 M triangles, baked -- the reference
+    has no instancing) on a 100 x 100 grid, the reference's tree built on the host, 7680 x 4320 at `aadepth 4` through the
+    full pixel path.  The reference's pattern shoots 16 samples per pixel of which 4 are distinct rays (both offsets use
+    `aax`, main.cpp:775-785); each distinct ray is traced once and weighted by its multiplicity."""
+    t0 = time.perf_counter()
+    s = rt.Scene()
+    for i in range(n_side):
+        for j in range(n_side):
+            s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0.0, i * 1.5, j * 1.5))
+    s.build_bvh()
+    ctx.upload(s)
+    host_s = time.perf_counter() - t0
+    c = n_side * 1.5 / 2
+    cam = rt.look_at((n_side * 1.5 * 0.6, c, c), (0.0, c, c))
+    w, h = 7680, 4320
+    bgr = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    entry = {"triangles": int(s.size()), "bvh_depth": int(s.bvh_depth()), "host_load_build_upload_s": round(host_s, 1)}
+    for prec, name in ((rt.RT_F64, "f64"), (rt.RT_F32, "f32")):
+        p = rt.default_params(width=w, height=h, precision=prec, aadepth=4, use_photon_map=0)
+        st = None
+        for _ in range(3):
+            r = ctx.render_dev(cam, p, (0, h), None, bgr.data_ptr(), stats=True)
+            if st is None or r.kernel_ms < st.kernel_ms:
+                st = r
+        entry[name] = {"distinct_camera_rays": int(st.primary_rays), "samples": int(4 * st.primary_rays), "device_ms": round(st.kernel_ms, 2),
+                       "Mrays_per_s": round(st.primary_rays / st.kernel_ms / 1e3, 1), "Msamples_per_s": round(4 * st.primary_rays / st.kernel_ms / 1e3, 1)}
+        if prec == rt.RT_F64:
+            stc = ctx.render_dev(cam, rt.default_params(width=w, height=h, aadepth=4, use_photon_map=0, count_work=1), (0, h), None, bgr.data_ptr(), stats=True)
+            if stc.inner_visits:
+                rays = st.primary_rays
+                flop = (rays + 2 * stc.inner_visits) * 21 + stc.prim_tests * 51
+                tf = flop / (st.trace_kernel_ms * 1e-3) / 1e12
+                entry["roofline"] = {"bound": "valu", "achieved": round(tf, 3), "peak": VALU_PEAK_TFLOPS["f64"], "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS["f64"], 4),
+                                     "kernels": "render_primary_kernel (16 M samples a launch)", "kernels_ms": round(st.trace_kernel_ms, 3), "flop_per_ray": round(flop / rays, 1),
+                                     "inner_visits_per_ray": round(stc.inner_visits / rays, 3), "prim_tests_per_ray": round(stc.prim_tests / rays, 3),
+                                     "hbm_priced": {"bytes_per_ray": round((stc.inner_visits * 128 + stc.prim_tests * 80) / rays, 1),
+                                                    "GBps": round((stc.inner_visits * 128 + stc.prim_tests * 80) / (st.trace_kernel_ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                                                    "note": "records the rays touch; the scene (0.9 GB of triangles, 0.1 GB of nodes in f64) is read through L1 and L2"}}
+    return entry
 
 
 def _shadow_rays(org, d, ids, t):
