@@ -14,8 +14,9 @@ resident in HBM before the timed region.  The output is one 32-bit word per pixe
 hit (-1: none), bit 30 set when the hit point lies in shadow.
 
 Rank 0 prints ONE JSON line.  metric = Mrays/s over all closest-hit queries (primary + shadow).
-For N > 1 the line also carries a strong-scaling figure for the full pixel path (glass teapot,
-3840x2160, depth 4: rows dealt over the GPUs, 8-bit frame gathered to rank 0).
+For N > 1 the line also carries strong-scaling figures for the full pixel path on BASELINE's two 8-GPU
+configurations (glass teapot, 3840x2160, depth 4; 10 M triangles, 7680x4320, 16 samples per pixel: rows dealt
+over the GPUs, 8-bit frame gathered to rank 0).
 """
 import argparse
 import json
@@ -185,11 +186,12 @@ def main():
     achieved_tflops = alg_flop / (avg_kernel_ms * 1e-3) / 1e12
 
     strong = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_STRONG") == "1":      # (the second form rehearses the leg on one GPU)
         try:
-            strong = strong_scaling_glass(rt, ctx, torch, dist, dev, world, rank, ext)
+            strong = strong_scaling(rt, ctx, torch, dist, dev, world, rank, ext, skip_c5=args.no_c5)
         except Exception as e:     # never lose the headline over it
             strong = {"error": repr(e)}
+        ctx.upload(scene)          # (the legs left their own scenes on the device)
 
     if rank != 0:
         if world > 1:
@@ -314,53 +316,94 @@ def main():
         raise SystemExit(1)
 
 
-def strong_scaling_glass(rt, ctx, torch, dist, dev, world, rank, ext):
-    """Strong scaling of the full pixel path on BASELINE's third configuration (glass teapot with smooth normals in the
-    box, 3840x2160, recursion depth 4, no photon map so that the time is all ray work): the frame's rows are dealt to the
+def build_glass_scene(rt):
+    """BASELINE's third configuration: the teapot with smooth normals as glass in the box."""
+    s = rt.Scene()
+    s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
+    s.add_cornell()
+    s.build_bvh()
+    return s, rt.look_at(CAM[:3], CAM[3:])
+
+
+def build_instanced_scene(rt, n_side=100):
+    """BASELINE's fifth configuration: n_side^2 copies of the teapot mesh on a grid, baked (the reference has no instancing),
+    seen from the side; the reference's tree, built on the host."""
+    s = rt.Scene()
+    for i in range(n_side):
+        for j in range(n_side):
+            s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0.0, i * 1.5, j * 1.5))
+    s.build_bvh()
+    c = n_side * 1.5 / 2
+    return s, rt.look_at((n_side * 1.5 * 0.6, c, c), (0.0, c, c))
+
+
+def strong_scaling_leg(rt, ctx, torch, dist, dev, world, rank, ext, what, build, w, h0, **params):
+    """Strong scaling of the full pixel path on one of BASELINE's 8-GPU configurations: the frame's rows are dealt to the
     ranks in bands of 8, every rank renders its bands to 8-bit pixels, rank 0 gathers 3 bytes per pixel over RCCL.
-    Collective call on every rank; returns the figures on every rank (rank 0 prints them)."""
+    Collective call on every rank; returns the figures on every rank (rank 0 prints them).  (With one rank -- a rehearsal
+    on a single GPU -- there is nothing to gather and no collective is called.)"""
     import time as _time
 
     from raytracer_amd import tiling
-    cam = rt.look_at(CAM[:3], CAM[3:])
-    w = 3840
     q = tiling.BAND * world
-    h = (2160 + q - 1) // q * q                          # whole bands for every rank: 2160 rows, or 2176 where 8 x ranks does not divide that
+    h = (h0 + q - 1) // q * q                            # whole bands for every rank: h0 rows, or a few more where 8 x ranks does not divide that
     rows = h // world
-    p = rt.default_params(width=w, height=h, use_photon_map=0, band_rows=tiling.BAND, n_parts=world, part=rank)
+    p = rt.default_params(width=w, height=h, use_photon_map=0, band_rows=tiling.BAND if world > 1 else 0, n_parts=world, part=rank, **params)
     failed, n_rays = None, 0.0
+    cam = None
     try:
-        s = rt.Scene()
-        s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
-        s.add_cornell(); s.build_bvh()
+        s, cam = build(rt)
         ctx.upload(s)
+        del s
         part = torch.empty((rows, w, 3), dtype=torch.uint8, device=dev)
-        recv = [torch.empty_like(part) for _ in range(world)] if rank == 0 else None
+        recv = [torch.empty_like(part) for _ in range(world)] if (rank == 0 and world > 1) else None
         st = ctx.render_dev(cam, p, (0, rows), None, part.data_ptr(), stats=True)          # warm-up: queues get allocated here
         n_rays = float(st.primary_rays + st.secondary_rays)
     except Exception as e:                               # (a rank that cannot set up must not leave the others waiting in a collective)
         failed = repr(e)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
     ok = torch.tensor([0.0 if failed else 1.0], dtype=torch.float64, device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if ok.item() < 1:
-        return {"error": failed or "set-up failed on another rank"}
     rays = torch.tensor([n_rays], dtype=torch.float64, device=dev)
-    dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+    if ok.item() < 1:
+        return {"workload": what, "error": failed or "set-up failed on another rank"}
     reps = 5
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    sync()
     t0 = _time.perf_counter()
     for _ in range(reps):
         ctx.render_dev(cam, p, (0, rows), None, part.data_ptr(), stats=False)
         done = torch.cuda.Event(); done.record(ext)
         torch.cuda.current_stream().wait_event(done)
         tiling.gather_to_rank0(part, world, rank, dist, recv)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    sync()
     dt = torch.tensor([(_time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     ctx.synchronize()
-    return {"workload": f"glass teapot_normal.obj + Cornell box, {w}x{h}, depth 4, full pixel path, 8-bit frame gathered to rank 0",
-            "scaling": "strong", "n_gpus": world, "rays_per_frame": int(rays.item()), "ms_per_frame": round(float(dt.item()) * 1e3, 3),
+    return {"workload": what, "scaling": "strong", "n_gpus": world, "rays_per_frame": int(rays.item()), "ms_per_frame": round(float(dt.item()) * 1e3, 3),
             "Mrays_per_s": round(float(rays.item()) / float(dt.item()) / 1e6, 1), "gather_bytes_per_frame": int(3 * w * h)}
+
+
+def strong_scaling(rt, ctx, torch, dist, dev, world, rank, ext, skip_c5=False):
+    """BASELINE's two 8-GPU configurations, whole-frame time by the slowest rank (wall clock around five frames, the
+    gather of each included)."""
+    out = {"glass_teapot_3840x2160_depth4": strong_scaling_leg(
+        rt, ctx, torch, dist, dev, world, rank, ext, "glass teapot_normal.obj + Cornell box, 3840x2160, depth 4, full pixel path, 8-bit frame gathered to rank 0",
+        build_glass_scene, 3840, 2160)}
+    if not skip_c5:
+        out["instanced_teapots_10M_triangles_7680x4320_16spp"] = strong_scaling_leg(
+            rt, ctx, torch, dist, dev, world, rank, ext,
+            "10 000 teapot meshes (9.92 M triangles), 7680x4320, aadepth 4 (16 samples per pixel, 4 distinct rays), full pixel path, 8-bit frame gathered to rank 0",
+            build_instanced_scene, 7680, 4320, aadepth=4)
+    return out
 
 
 def other_configs(rt, ctx, torch, dev, skip_c5=False):
@@ -382,9 +425,7 @@ def other_configs(rt, ctx, torch, dev, skip_c5=False):
                 st = s
         return st
 
-    s3 = rt.Scene()
-    s3.load_obj(os.path.join(DATA, "teapot_normal.obj"), (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
-    s3.add_cornell(); s3.build_bvh()
+    s3, _ = build_glass_scene(rt)
     ctx.upload(s3)
     w, h = 3840, 2160
     st = best(rt.default_params(width=w, height=h, use_photon_map=0), w, h)
@@ -436,15 +477,9 @@ def config5(rt, ctx, torch, dev, n_side=100):
     full pixel path.  The reference's pattern shoots 16 samples per pixel of which 4 are distinct rays (both offsets use
     `aax`, main.cpp:775-785); each distinct ray is traced once and weighted by its multiplicity."""
     t0 = time.perf_counter()
-    s = rt.Scene()
-    for i in range(n_side):
-        for j in range(n_side):
-            s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0.0, i * 1.5, j * 1.5))
-    s.build_bvh()
+    s, cam = build_instanced_scene(rt, n_side)
     ctx.upload(s)
     host_s = time.perf_counter() - t0
-    c = n_side * 1.5 / 2
-    cam = rt.look_at((n_side * 1.5 * 0.6, c, c), (0.0, c, c))
     w, h = 7680, 4320
     bgr = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
     entry = {"triangles": int(s.size()), "bvh_depth": int(s.bvh_depth()), "host_load_build_upload_s": round(host_s, 1)}
