@@ -184,20 +184,6 @@ int read_counters(rt_context* ctx, rtk::TraceCounters* out)
     return RT_OK;
 }
 
-template <class R>
-int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* d_dir, double* d_dist, int32_t* d_ids)
-{
-    int cap = stack_cap(ctx);
-    size_t lds = rtk::stack_lds_bytes(cap, sizeof(float));
-    if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
-    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
-    int blocks = (int)std::max<int64_t>(1, (n + rtk::BLOCK - 1) / rtk::BLOCK);   // one chunk of 64 rays per wave
-    hipLaunchKernelGGL((rtk::trace_batch_kernel<R>), dim3(blocks), dim3(rtk::BLOCK), lds, ctx->stream, view<R>(ctx), (long long)n, d_org,
-                       d_dir, d_dist, d_ids, (rtk::TraceCounters*)ctx->counters.p, cap);
-    HIP_TRY(hipGetLastError());
-    return RT_OK;
-}
-
 // A launch with more than 64 KiB of dynamic LDS has to be allowed per kernel and device first.  The call is made once per
 // (device, kernel, size reached): between the launches of a frame it would leave the GPU waiting for the host.
 int allow_dynamic_lds(const rt_context* ctx, const void* kernel, size_t bytes)
@@ -262,6 +248,33 @@ int trace_geometry(const rt_context* ctx, int n_nodes, TraceGeom* g, int vgpr_wa
                 best_mode == rtk::TRAV_NODES ? node_bytes : (size_t)0, best_mode, ctx->depth, vgpr_waves);
     *g = TraceGeom{best_w * 64, 0, lds, best_mode};
     return RT_OK;
+}
+
+// BVH::Shoot for a batch of rays: the same choice of stack form and node staging as the pixel kernels make.
+template <class R, bool TRI_ONLY>
+int launch_batch_t(rt_context* ctx, int64_t n, const double* d_org, const double* d_dir, double* d_dist, int32_t* d_ids)
+{
+    const int cap = stack_cap(ctx);
+    TraceGeom g;
+    int rc = trace_geometry<R>(ctx, ctx->n_nodes, &g, 16);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
+    const int blocks = (int)std::max<int64_t>(1, (n + g.threads - 1) / g.threads);   // one chunk of 64 rays per wave
+#define RT_LAUNCH_BATCH(MODE)                                                                                                                       \
+    hipLaunchKernelGGL((rtk::trace_batch_kernel<R, TRI_ONLY, MODE>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), (long long)n, d_org, \
+                       d_dir, d_dist, d_ids, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes)
+    if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_BATCH(rtk::TRAV_NODES);
+    else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_BATCH(rtk::TRAV_RETEST);
+    else RT_LAUNCH_BATCH(rtk::TRAV_PLAIN);
+#undef RT_LAUNCH_BATCH
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+template <class R>
+int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* d_dir, double* d_dist, int32_t* d_ids)
+{
+    return view<R>(ctx).tri_only ? launch_batch_t<R, true>(ctx, n, d_org, d_dir, d_dist, d_ids) : launch_batch_t<R, false>(ctx, n, d_org, d_dir, d_dist, d_ids);
 }
 
 template <class R, bool COUNT, bool TRI_ONLY>

@@ -345,13 +345,15 @@ __device__ __forceinline__ void latch_overflow(void* counters, int which)
 struct TraceCounters { unsigned long long next, overflow, shadow, inner, prims, pad[3]; };
 
 // Batch form of BVH::Shoot: rays in SoA doubles (x[n], y[n], z[n]).
-template <class R>
-__global__ __launch_bounds__(BLOCK) void trace_batch_kernel(rtf::SceneView<R> sv, long long n, const double* __restrict__ org,
-                                                            const double* __restrict__ dir, double* __restrict__ dist_io,
-                                                            int* __restrict__ ids, TraceCounters* ctr, int cap)
+template <class R, bool TRI_ONLY, int MODE>
+__global__ __launch_bounds__(MAX_BLOCK) void trace_batch_kernel(rtf::SceneView<R> sv, long long n, const double* __restrict__ org,
+                                                                const double* __restrict__ dir, double* __restrict__ dist_io,
+                                                                int* __restrict__ ids, TraceCounters* ctr, int cap, int n_nodes)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    LaneStack st = make_stack<R>(lds, cap);
+    const size_t node_bytes = MODE == TRAV_NODES ? node_lds_bytes<R>((size_t)n_nodes) : 0;
+    if (MODE == TRAV_NODES) stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    LaneStack st = make_stack<R>(lds, cap, node_bytes);
     uint32_t overflow = 0;
     // one chunk of 64 rays per wave; the dispatcher balances the load
     long long i = ((long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * WAVE + st.lane;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(BLOCK) void trace_batch_kernel(rtf::SceneView<R> sv
         R o[3] = {(R)org[i], (R)org[n + i], (R)org[2 * n + i]};
         R d[3] = {(R)dir[i], (R)dir[n + i], (R)dir[2 * n + i]};
         R dist = (R)dist_io[i];
-        int id = trace_ray<R>(sv, o, d, dist, st, &overflow);
+        int id = trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dist, st, &overflow);
         ids[i] = id;
         if (id >= 0) dist_io[i] = (double)dist;
     }
