@@ -620,8 +620,9 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
 {
     int rc;
     const int cap = stack_cap(ctx);
-    const size_t lds = rtk::stack_lds_bytes(cap, sizeof(float));
-    if (lds > 160 * 1024) return fail(RT_ERR_LIMIT, "BVH depth %d needs %zu B of LDS stack (> 160 KiB)", ctx->depth, lds);
+    TraceGeom g;
+    if ((rc = trace_geometry<double>(ctx, ctx->n_nodes, &g, 12))) return rc;
+    const bool tri_only = ctx->v64.tri_only != 0;
     const int64_t batch = 1 << 20;
     // a photon stores at most once per bounce level, and scatters at most 4 volume photons (a subsurface hit ends the walk)
     const unsigned long long cap_s = ((unsigned long long)batch * (bounce + 1) + rtq::SHARDS - 1) / rtq::SHARDS + 16384;
@@ -649,9 +650,20 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
         // one launch per bounce; a later bounce's grid is sized for all photons and the lanes beyond the survivors leave at once
         rte::PhotonState* lists[2] = {(rte::PhotonState*)ctx->rays.p, (rte::PhotonState*)ctx->gq.p};
         for (int b = 0; b <= bounce; b++) {
-            hipLaunchKernelGGL((rte::emit_kernel<double>), dim3((unsigned)((a.n_emit + rtk::BLOCK - 1) / rtk::BLOCK)), dim3(rtk::BLOCK), lds, ctx->stream,
-                               ctx->v64, sd, a, b, (const rte::PhotonState*)lists[b & 1], lists[(b + 1) & 1], (rte::PhotonOut*)ctx->hits_a.p, cap_s,
-                               (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap);
+#define RT_LAUNCH_EMIT(TRI, MODE)                                                                                                                       \
+    hipLaunchKernelGGL((rte::emit_kernel<double, TRI, MODE>), dim3((unsigned)((a.n_emit + g.threads - 1) / g.threads)), dim3(g.threads), g.lds, ctx->stream, \
+                       ctx->v64, sd, a, b, (const rte::PhotonState*)lists[b & 1], lists[(b + 1) & 1], (rte::PhotonOut*)ctx->hits_a.p, cap_s,               \
+                       (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap, ctx->n_nodes)
+            if (tri_only) {
+                if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_EMIT(true, rtk::TRAV_NODES);
+                else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_EMIT(true, rtk::TRAV_RETEST);
+                else RT_LAUNCH_EMIT(true, rtk::TRAV_PLAIN);
+            } else {
+                if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_EMIT(false, rtk::TRAV_NODES);
+                else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_EMIT(false, rtk::TRAV_RETEST);
+                else RT_LAUNCH_EMIT(false, rtk::TRAV_PLAIN);
+            }
+#undef RT_LAUNCH_EMIT
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));

@@ -73,13 +73,15 @@ struct LaneRng {
 // One bounce of every photon still walking (main.cpp:396-600), one photon per lane.  Bounce 0 starts the photons at the
 // light; a later bounce takes the survivors of the one before, compacted: walks end at very different lengths, and a wave
 // that carried its photons from the light to their ends ran with a sixth of its lanes on average.
-template <class R>
+template <class R, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> sv, ShadeTables sd, EmitArgs a, int bounce, const PhotonState* __restrict__ from,
                                                              PhotonState* __restrict__ onward, PhotonOut* __restrict__ surf, unsigned long long cap_s,
-                                                             PhotonOut* __restrict__ vol, unsigned long long cap_v, EmitCounters* ctr, int cap)
+                                                             PhotonOut* __restrict__ vol, unsigned long long cap_v, EmitCounters* ctr, int cap, int n_nodes)
 {
     extern __shared__ __align__(16) unsigned char lds[];
-    LaneStack st = rtk::make_stack<R>(lds, cap);
+    const size_t node_bytes = MODE == rtk::TRAV_NODES ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
+    if (MODE == rtk::TRAV_NODES) rtk::stage_nodes<R>(reinterpret_cast<uint4*>(lds), sv.nodes, n_nodes);
+    LaneStack st = rtk::make_stack<R>(lds, cap, node_bytes);
     uint32_t ovf_stack = 0;
     unsigned long long ovf_queue = 0, n_rays = 0;
     const double PI_REF = 3.1415926;   // main.cpp:24
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> 
         if (alive) {
             R o[3] = {(R)org.x, (R)org.y, (R)org.z}, d[3] = {(R)dir.x, (R)dir.y, (R)dir.z};
             R dd = R(1e9);
-            io = rtk::trace_ray<R>(sv, o, d, dd, st, &ovf_stack);      // main.cpp:402
+            io = rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, o, d, dd, st, &ovf_stack);      // main.cpp:402
             dist = (double)dd;
             n_rays++;
             if (io < 0 || !(dist > a.accuracy)) alive = false;        // main.cpp:407
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> 
                     R po[3] = {(R)pos.x, (R)pos.y, (R)pos.z}, pd[3] = {(R)sdir.x, (R)sdir.y, (R)sdir.z};
                     R range = (R)step;
                     n_rays++;
-                    if (rtk::trace_ray<R>(sv, po, pd, range, st, &ovf_stack) >= 0) {   // main.cpp:584-586: left the volume
+                    if (rtk::trace_ray<R, false, TRI_ONLY, MODE>(sv, po, pd, range, st, &ovf_stack) >= 0) {   // main.cpp:584-586: left the volume
                         scatter = false;
                     } else {
                         pos = rtm::vadd(pos, rtm::vmul(sdir, step));
