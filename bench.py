@@ -185,6 +185,30 @@ def main():
     alg_flop = (rank_rays + 2 * st_work.inner_visits) * 21 + st_work.prim_tests * 51
     achieved_tflops = alg_flop / (avg_kernel_ms * 1e-3) / 1e12
 
+    # ---- informational: the same frames from two contexts (two streams) of this GPU taking turns, so that the last blocks of
+    # one launch run beside the first of the next (never `value`: a step is one launch on one stream)
+    two_ctx = None
+    if world == 1:
+        try:
+            ctx2 = rt.Context(dev_index)
+            ctx2.upload(scene)
+            buf2 = torch.empty_like(buf)
+            pair = ((ctx, buf), (ctx2, buf2))
+            for i in range(2 * max(args.warmup, 2)):
+                pair[i & 1][0].trace_primary_dev(cam, params, (0, part_rows), pair[i & 1][1].data_ptr(), None, None, stats=False)
+            ctx.synchronize(); ctx2.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                pair[i & 1][0].trace_primary_dev(cam, params, (0, part_rows), pair[i & 1][1].data_ptr(), None, None, stats=False)
+            ctx.synchronize(); ctx2.synchronize()
+            dt2 = time.perf_counter() - t0
+            two_ctx = {"ms_per_step": round(dt2 / args.steps * 1e3, 4), "Mrays_per_s": round(rays_per_step * args.steps / dt2 / 1e6, 2),
+                       "frames_equal": bool(torch.equal(buf, buf2)),
+                       "note": "two contexts of one GPU render alternate frames on their own streams; wall clock over the same number of steps"}
+            del ctx2
+        except Exception as e:
+            two_ctx = {"error": repr(e)}
+
     strong = None
     if world > 1 or os.environ.get("BENCH_FORCE_STRONG") == "1":      # (the second form rehearses the leg on one GPU)
         try:
@@ -301,6 +325,7 @@ def main():
             "note": ("hit ids of the f32 instantiation differ from the reference's (f64) on the fraction of pixels given in "
                      "parity.f32_id_mismatch_fraction (silhouettes); they equal the single-precision restatement's exactly"),
         },
+        "two_contexts_alternating": two_ctx,
         "cpu_baseline": cpu,
         "parity": parity,
         "other_configs": extras,
