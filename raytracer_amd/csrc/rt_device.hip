@@ -1575,6 +1575,19 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
             resident_lds = image + resident_waves * per_wave;
         }
     }
+    // Scenes of a few thousand triangles: the node image alone beside the stacks (up to ~100 KB of it), primitives through L1 --
+    // a third of the records a diverging wave fetches are nodes.
+    int nodes_waves = 0;
+    size_t nodes_lds = 0;
+    if (MODE == rtk::TRAV_PLAIN && ctx->n_nodes > 0 && !getenv("RT_NO_SCENE_LDS")) {
+        const size_t image = rtk::node_lds_bytes<R>((size_t)ctx->n_nodes);
+        const size_t per_wave = rtk::stack_lds_bytes(cap, sizeof(float), 1);
+        if (image + 12 * per_wave <= 160 * 1024) {
+            nodes_waves = (int)std::min<size_t>(14, (160 * 1024 - image) / per_wave);
+            if (const char* e = getenv("RT_SCENE_WAVES")) nodes_waves = std::max(1, std::min(nodes_waves, atoi(e)));      // tuning aid
+            nodes_lds = image + nodes_waves * per_wave;
+        }
+    }
     rtr::HitRec* qin = (rtr::HitRec*)ctx->hits_a.p;
     rtr::HitRec* qout = (rtr::HitRec*)ctx->hits_b.p;
     for (int level = 1; level <= levels; level++) {
@@ -1590,6 +1603,10 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
             if (MODE == rtk::TRAV_NODES && resident_waves > 0) {
                 if (int rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::trace_queue_kernel<R, TRI_ONLY, rtk::TRAV_SCENE, COUNT>), resident_lds)) return rc_lds;
                 hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, rtk::TRAV_SCENE, COUNT>), dim3(ctx->num_cus), dim3(resident_waves * 64), resident_lds, ctx->stream,
+                                   view<R>(ctx), a, level, (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes, ctx->n_prims);
+            } else if (MODE == rtk::TRAV_PLAIN && nodes_waves > 0) {
+                if (int rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::trace_queue_kernel<R, TRI_ONLY, rtk::TRAV_NODES, COUNT>), nodes_lds)) return rc_lds;
+                hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, rtk::TRAV_NODES, COUNT>), dim3(ctx->num_cus), dim3(nodes_waves * 64), nodes_lds, ctx->stream,
                                    view<R>(ctx), a, level, (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes, ctx->n_prims);
             } else
                 hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE, COUNT>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,

@@ -444,17 +444,21 @@ def test_no_photon_map_traces_the_same_rays(gpu_ctx, head_quirk):
 
 
 @pytest.mark.parametrize("precision", ["f64", "f32"])
-@pytest.mark.parametrize("mixed", [False, True])
-def test_queue_tracer_scene_in_lds_same_frame(gpu_ctx, monkeypatch, precision, mixed):
-    """Small scenes are traced from LDS by the queue tracer (nodes and primitive records staged once per block), larger
-    ones through L1: the same walk on the same records, so switching the staging off changes nothing -- the same rays
-    and the same frame up to the order of the per-pixel sums.  Triangles only and mixed primitives (the two
-    instantiations of the leaf test), both precisions."""
-    if mixed:
+@pytest.mark.parametrize("which", ["teapot", "mixed", "water"])
+def test_queue_tracer_scene_in_lds_same_frame(gpu_ctx, monkeypatch, precision, which):
+    """Small scenes are traced from LDS by the queue tracer (nodes and primitive records staged once per block), scenes
+    of a few thousand triangles with their nodes in LDS, larger ones through L1: the same walk on the same records, so
+    switching the staging off changes nothing -- the same rays and the same frame up to the order of the per-pixel
+    sums.  Triangles only and mixed primitives (the two instantiations of the leaf test), the water surface (nodes
+    only), both precisions."""
+    if which == "mixed":
         s = _random_scene(rt.Scene(), 21)
     else:
         s = rt.Scene()
-        s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
+        if which == "teapot":
+            s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
+        else:
+            s.load_obj(os.path.join(DATA, "water.obj"), (0.26, 0.84, 1.0, 1.8), 1.33, (0, 0, 0))
         s.add_cornell()
         s.build_bvh()
     gpu_ctx.upload(s)
