@@ -1569,8 +1569,8 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
         const size_t image = rtk::node_lds_bytes<R>((size_t)ctx->n_nodes) + rtk::prim_lds_bytes<R>((size_t)ctx->n_prims);
         const size_t per_wave = rtk::stack_lds_bytes(cap, sizeof(float), 1);
         if (image + 8 * per_wave <= 160 * 1024) {
-            // (at most 14: a block of 16 waves measured a third slower than one of 14 -- the float glass frame 1.39 ms against 1.03)
-            resident_waves = (int)std::min<size_t>(14, (160 * 1024 - image) / per_wave);
+            // (at most 15: a block of 16 waves measured a third slower -- the float glass frame 1.39 ms against 1.02)
+            resident_waves = (int)std::min<size_t>(15, (160 * 1024 - image) / per_wave);
             if (const char* e = getenv("RT_SCENE_WAVES")) resident_waves = std::max(1, std::min(resident_waves, atoi(e)));      // tuning aid
             resident_lds = image + resident_waves * per_wave;
         }
@@ -1583,7 +1583,7 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
         const size_t image = rtk::node_lds_bytes<R>((size_t)ctx->n_nodes);
         const size_t per_wave = rtk::stack_lds_bytes(cap, sizeof(float), 1);
         if (image + 12 * per_wave <= 160 * 1024) {
-            nodes_waves = (int)std::min<size_t>(14, (160 * 1024 - image) / per_wave);
+            nodes_waves = (int)std::min<size_t>(15, (160 * 1024 - image) / per_wave);
             if (const char* e = getenv("RT_SCENE_WAVES")) nodes_waves = std::max(1, std::min(nodes_waves, atoi(e)));      // tuning aid
             nodes_lds = image + nodes_waves * per_wave;
         }
