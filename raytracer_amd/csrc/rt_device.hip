@@ -647,13 +647,29 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
         a.accuracy = accuracy;
         HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(rte::EmitCounters), ctx->stream));
         HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        // the photons of the launch in the order of their starting directions (which photons share a wave at the first bounce)
+        const uint32_t* order = nullptr;
+        if (a.n_emit >= 4096 && !getenv("RT_EMIT_UNORDERED")) {
+            const int ne = (int)a.n_emit;
+            const size_t a4 = ((size_t)ne * 4 + 255) & ~(size_t)255;
+            size_t sort_bytes = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ne, 0,
+                                                       rte::EMIT_ORDER_KEY_BITS, ctx->stream));
+            if ((rc = ctx->kd_work.reserve(4 * a4 + sort_bytes + 256))) return rc;
+            char* w = (char*)ctx->kd_work.p;
+            uint32_t *k0 = (uint32_t*)w, *k1 = (uint32_t*)(w + a4), *v0 = (uint32_t*)(w + 2 * a4), *v1 = (uint32_t*)(w + 3 * a4);
+            hipLaunchKernelGGL(rte::emit_order_keys_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, ctx->stream, a, k0, v0);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + 4 * a4, sort_bytes, k0, k1, v0, v1, ne, 0, rte::EMIT_ORDER_KEY_BITS, ctx->stream));
+            order = v1;
+        }
         // one launch per bounce; a later bounce's grid is sized for all photons and the lanes beyond the survivors leave at once
         rte::PhotonState* lists[2] = {(rte::PhotonState*)ctx->rays.p, (rte::PhotonState*)ctx->gq.p};
         for (int b = 0; b <= bounce; b++) {
 #define RT_LAUNCH_EMIT(TRI, MODE)                                                                                                                       \
     hipLaunchKernelGGL((rte::emit_kernel<double, TRI, MODE>), dim3((unsigned)((a.n_emit + g.threads - 1) / g.threads)), dim3(g.threads), g.lds, ctx->stream, \
                        ctx->v64, sd, a, b, (const rte::PhotonState*)lists[b & 1], lists[(b + 1) & 1], (rte::PhotonOut*)ctx->hits_a.p, cap_s,               \
-                       (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap, ctx->n_nodes)
+                       (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap, ctx->n_nodes, order)
             if (tri_only) {
                 if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_EMIT(true, rtk::TRAV_NODES);
                 else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_EMIT(true, rtk::TRAV_RETEST);

@@ -70,13 +70,48 @@ struct LaneRng {
     }
 };
 
+// The direction a photon leaves the light with (main.cpp:702-708: uniform in the unit ball by rejection, then normalised);
+// takes the first draws of the photon's stream.
+__device__ __forceinline__ D3 start_direction(LaneRng& rng)
+{
+    double x, y, z;
+    do { x = 2 * rng.unit() - 1; y = 2 * rng.unit() - 1; z = 2 * rng.unit() - 1; } while (x * x + y * y + z * z > 1);
+    return rtm::vnorm(D3{x, y, z});
+}
+
+// Which photons share a wave at the first bounce: the photons of a launch ordered by the direction they start with (a
+// key per photon: cube face, then a 6 + 6 bit Morton code of the point on the face), so that the 64 rays of a wave leave
+// the light side by side like the camera rays of a tile instead of in 64 unrelated directions.  What a photon does does
+// not depend on its lane, and the photon list is put into (photon, bounce) order afterwards: the list is the same.
+__global__ void emit_order_keys_kernel(EmitArgs a, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n_emit) return;
+    const unsigned long long pn = (unsigned long long)(a.first + i);
+    LaneRng rng{(uint32_t)pn ^ a.seed * 0x9E3779B9u, (uint32_t)(pn >> 32) + a.seed, 0u};
+    const D3 d = start_direction(rng);
+    const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    uint32_t face;
+    double u, v, m;
+    if (ax >= ay && ax >= az) { face = d.x < 0 ? 1u : 0u; m = ax; u = d.y; v = d.z; }
+    else if (ay >= az) { face = d.y < 0 ? 3u : 2u; m = ay; u = d.x; v = d.z; }
+    else { face = d.z < 0 ? 5u : 4u; m = az; u = d.x; v = d.y; }
+    const uint32_t qu = (uint32_t)fmin(63.0, (u / m * 0.5 + 0.5) * 64.0), qv = (uint32_t)fmin(63.0, (v / m * 0.5 + 0.5) * 64.0);
+    uint32_t mort = 0;
+    for (int b = 0; b < 6; b++) mort |= ((qu >> b) & 1u) << (2 * b) | ((qv >> b) & 1u) << (2 * b + 1);
+    keys[i] = face << 12 | mort;
+    vals[i] = (uint32_t)i;
+}
+constexpr int EMIT_ORDER_KEY_BITS = 15;
+
 // One bounce of every photon still walking (main.cpp:396-600), one photon per lane.  Bounce 0 starts the photons at the
 // light; a later bounce takes the survivors of the one before, compacted: walks end at very different lengths, and a wave
 // that carried its photons from the light to their ends ran with a sixth of its lanes on average.
 template <class R, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> sv, ShadeTables sd, EmitArgs a, int bounce, const PhotonState* __restrict__ from,
                                                              PhotonState* __restrict__ onward, PhotonOut* __restrict__ surf, unsigned long long cap_s,
-                                                             PhotonOut* __restrict__ vol, unsigned long long cap_v, EmitCounters* ctr, int cap, int n_nodes)
+                                                             PhotonOut* __restrict__ vol, unsigned long long cap_v, EmitCounters* ctr, int cap, int n_nodes,
+                                                             const uint32_t* __restrict__ order)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     const size_t node_bytes = MODE == rtk::TRAV_NODES ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
@@ -99,14 +134,10 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> 
         for (int i = 0; i < 3; i++) light[i] = ps.light[i];
         pn = ps.pn; draws = ps.draws;
     } else if (alive) {
-        pn = (unsigned long long)(a.first + local);
+        pn = (unsigned long long)(a.first + (order ? (long long)order[local] : local));      // (see emit_order_keys_kernel)
     }
     LaneRng rng{(uint32_t)pn ^ a.seed * 0x9E3779B9u, (uint32_t)(pn >> 32) + a.seed, draws};
-    if (alive && bounce == 0) {   // main.cpp:702-708: uniform in the unit ball by rejection, then normalised
-        double x, y, z;
-        do { x = 2 * rng.unit() - 1; y = 2 * rng.unit() - 1; z = 2 * rng.unit() - 1; } while (x * x + y * y + z * z > 1);
-        dir = rtm::vnorm(D3{x, y, z});
-    }
+    if (alive && bounce == 0) dir = start_direction(rng);
 
     {      // (main.cpp:398: depth > BOUNCE ends the walk -- the host launches bounces 0 .. BOUNCE)
         int io = -1;

@@ -562,7 +562,7 @@ def _emission_summary(ph):
 
 @pytest.mark.parametrize("tag,rgbs,ior", [("glass", (1.0, 1.0, 1.0, 1.8), 1.5), ("mirror", (1.0, 1.0, 1.0, 0.9), 1.5),
                                           ("subsurface", (0.9, 0.7, 0.6, -1.0), 1.3)])
-def test_gpu_emission_statistics(gpu_ctx, tag, rgbs, ior):
+def test_gpu_emission_statistics(gpu_ctx, tag, rgbs, ior, monkeypatch):
     """photonEmission on the GPU (per-photon random streams) against the serial host emission that
     reproduces the reference's list: same distribution -- photons stored per emitted photon, mean
     power, where the photons land -- within sampling noise; identical lists for identical arguments."""
@@ -577,6 +577,13 @@ def test_gpu_emission_statistics(gpu_ctx, tag, rgbs, ior):
     s.photons_clear()
     s.emit_photons_gpu(gpu_ctx, n, seed=5)
     assert np.array_equal(s.photons_get(0), dev[0]) and np.array_equal(s.photons_get(1), dev[1])   # launch-independent order
+    # which photons share a wave (the launch orders them by starting direction) does not change the list
+    s.photons_clear()
+    monkeypatch.setenv("RT_EMIT_UNORDERED", "1")
+    st_plain = s.emit_photons_gpu(gpu_ctx, n, seed=5)
+    monkeypatch.delenv("RT_EMIT_UNORDERED")
+    assert st_plain.secondary_rays == st.secondary_rays
+    assert np.array_equal(s.photons_get(0), dev[0]) and np.array_equal(s.photons_get(1), dev[1])
     assert st.secondary_rays >= n
     for which in (0, 1):
         nh, ph_, hh = _emission_summary(host[which])
