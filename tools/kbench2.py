@@ -1,0 +1,25 @@
+"""trace_primary on the bench frame by shadow mode and precision (development aid): 0 none, 1 shadow ids (full walk),
+2 folded bit (occlusion query)."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+torch.cuda.init()
+import raytracer_amd as rt
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+mesh = sys.argv[1] if len(sys.argv) > 1 else "teapot1.obj"
+s = rt.Scene(); s.load_obj(os.path.join(DATA, mesh)); s.add_cornell(); s.build_bvh()
+ctx = rt.Context(0); ctx.upload(s)
+cam = rt.look_at((2.8, 0, 0), (0, 0, 0))
+w, h = 1920, 1080
+buf = torch.empty((2, h, w), dtype=torch.int32, device="cuda")
+for prec, name in ((rt.RT_F64, "f64"), (rt.RT_F32, "f32")):
+    for shadow in (0, 1, 2):
+        p = rt.default_params(width=w, height=h, precision=prec, shadow_rays=shadow)
+        ms = []
+        for i in range(40):
+            st = ctx.trace_primary_dev(cam, p, (0, h), buf[0].data_ptr(), None, buf[1].data_ptr() if shadow == 1 else None)
+            if i >= 10:
+                ms.append(st.trace_kernel_ms)
+        print(f"{mesh} {name} shadow={shadow}: median {np.median(ms):.4f} ms, rays {st.primary_rays + st.shadow_rays}", flush=True)
