@@ -43,6 +43,33 @@ def test_batch_rays_bit_exact(gpu_ctx, scenes, tag):
         assert eq(ids, h["ids"]) and eq(t, h["t"])
 
 
+@pytest.mark.parametrize("env", [{"RT_TRAV_MODE": "retest"}, {"RT_TRAV_MODE": "plain", "RT_NO_NODE_LDS": "1"}, {"RT_TRAV_MODE": "plain", "RT_BLOCK_WAVES": "2"}])
+def test_every_stack_form_bit_exact(gpu_ctx, scenes, monkeypatch, env):
+    """The library picks the form of the traversal stack and whether the node array is staged in LDS from the tree's
+    depth and size; each form, forced here, gives the reference's hits on the golden rays (batch entry point, bounded and
+    axis-parallel rays included) and on a golden frame (pixel entry point)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    gpu_ctx.upload(scenes["teapot_normal"])
+    g = golden("rays_teapot_normal.npz")
+    for prec in (rt.RT_F64,):
+        ids, t = gpu_ctx.trace_closest(g["org"], g["dir"], precision=prec)
+        assert eq(ids, g["ids"]) and eq(t, g["t"])
+        ids, t = gpu_ctx.trace_closest(g["org"], g["dir"], g["max_dist"], precision=prec)
+        assert eq(ids, g["ids_bounded"]) and eq(t, g["t_bounded"])
+        ids, t = gpu_ctx.trace_closest(g["org_axis"], g["dir_axis"], precision=prec)
+        assert eq(ids, g["ids_axis"]) and eq(t, g["t_axis"])
+    h = golden("hits_teapot_normal_96x54.npz")
+    ids, t, _, _ = gpu_ctx.trace_primary(rt.look_at(CAM[:3], CAM[3:]), rt.default_params(width=96, height=54))
+    assert eq(ids.ravel(), h["ids"].ravel()) and eq(np.where(ids >= 0, t, 1e9).ravel(), h["t"].ravel())
+    # the float walk in the same form equals the float walk in the form the library would pick
+    ids32, t32 = gpu_ctx.trace_closest(g["org"], g["dir"], precision=rt.RT_F32)
+    for k in env:
+        monkeypatch.delenv(k)
+    ref32, reft32 = gpu_ctx.trace_closest(g["org"], g["dir"], precision=rt.RT_F32)
+    assert eq(ids32, ref32) and eq(t32, reft32)
+
+
 @pytest.mark.parametrize("tag", ["teapot_normal", "water"])
 def test_primary_1920x1080_hash(gpu_ctx, scenes, tag):
     """The full-size id map: hash, hit counts and sha256 of the t image equal the compiled reference's."""
