@@ -130,6 +130,7 @@ struct rt_context {
     bool has_scene = false;
     bool has_glossy = false;  // some material takes the 16-sample loops of main.cpp:177-257
     bool has_bounce = false;  // some material reflects, refracts or scatters below the surface (special != 0): hits can queue rays
+    bool has_sss = false;     // some material scatters below the surface (special < 0)
     DevBuf counters;          // rtk::TraceCounters / rtr::RenderCounters
     DevBuf ctr_log;           // the counter blocks of a frame's row chunks, fetched once at its end
     // photon maps in HBM (0 surface, 1 volume)
@@ -941,10 +942,11 @@ int upload_shading(rt_context* ctx, const rth::Scene& s)
     int rc;
     std::vector<rtf::ObjShade> sh(s.objects.size());
     std::vector<unsigned char> live(sh.size());
-    ctx->has_glossy = ctx->has_bounce = false;
+    ctx->has_glossy = ctx->has_bounce = ctx->has_sss = false;
     for (size_t i = 0; i < sh.size(); i++) {
         sh[i] = s.objects[i].sh;
         if (sh[i].color[3] != 0.0) ctx->has_bounce = true;
+        if (sh[i].color[3] < 0.0) ctx->has_sss = true;
         if (rtm::glossy_special(sh[i].color[3])) ctx->has_glossy = true;
         // (a textured triangle takes its colour from the map, whose `special` is 0: see rtm::obj_color)
         const bool textured = sh[i].kind == rtf::PRIM_TRI && sh[i].has_texture && sh[i].map >= 0;
@@ -1509,20 +1511,25 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     if (const char* e = getenv("RT_GATHER_MIN_LANES")) gpt.min_lanes = atoi(e);
     if (const char* e = getenv("RT_GATHER_ROUNDS")) gpt.max_rounds = atoi(e);
 
+    // Subsurface materials: the group kernel forms their surface estimates and leaves them in the requests' records for the
+    // per-request kernel, which therefore only runs after it (no launch alongside: a record being completed must not be read).
+    const bool sss_scene = ctx->has_sss && !getenv("RT_SSS_PER_REQUEST");      // (the switch: comparison runs)
     rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, windows_done, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
-                     prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
+                     sss_scene ? 1 : 0, prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));      // (the queue and the counters are ready here)
     hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc);
     HIP_TRY(hipGetLastError());
     // The per-request kernel alongside, on the second stream.  Its waves stay only once every wave of the group kernel
     // has begun, so they never hold a place the group kernel waits for; six blocks per CU leave room for one of the
     // group kernel's in any case.
-    HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-    hipLaunchKernelGGL(rtg::gather_alongside_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->side, ctx->pm[0], ctx->pm[1], recs, d_redo,
-                       (uint32_t)std::min<size_t>(redo_entries, 0xFFFFFFFFu), cnt, shard_cap, (const unsigned long long*)windows_done, (unsigned)(ctx->num_cus * 8),
-                       next_gather, gp, d_acc);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+    if (!sss_scene) {
+        HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        hipLaunchKernelGGL(rtg::gather_alongside_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->side, ctx->pm[0], ctx->pm[1], recs, d_redo,
+                           (uint32_t)std::min<size_t>(redo_entries, 0xFFFFFFFFu), cnt, shard_cap, (const unsigned long long*)windows_done, (unsigned)(ctx->num_cus * 8),
+                           next_gather, gp, d_acc);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+    }
     if (prof) {
         unsigned long long v[rtg::TP_SLOTS];
         HIP_TRY(hipMemcpyAsync(v, ctx->st_aux.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
@@ -1538,7 +1545,7 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, d_redo,
                        (const unsigned long long*)n_redo, next_gather, gp, d_acc);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // what follows on the stream follows both
+    if (!sss_scene) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // what follows on the stream follows both
     return RT_OK;
 }
 

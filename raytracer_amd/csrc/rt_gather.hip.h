@@ -54,6 +54,9 @@ struct GatherRec {
     double march[3];             // refracted direction the volume march follows (main.cpp:339)
 };
 constexpr uint32_t GATHER_SSS = 1u, GATHER_MARCH = 2u;
+// A subsurface request whose surface estimate (main.cpp:260-295, before the clip) the group kernel has already formed: it
+// stands in the record's `normal`, which nothing else needs any more; the per-request kernel adds the volume terms.
+constexpr uint32_t GATHER_SURFACE_DONE = 4u;
 
 // Optional cycle accounting (development aid): slots of the array a kernel is given.
 enum ProfSlot { P_DESCENT, P_SCAN0, P_SELECT, P_N_SELECT, P_ROUNDS, P_N_ROUNDS, P_LEAVES, P_N_LEAVES, P_ESTIMATE, P_QUERIES, P_SLOTS };
@@ -798,11 +801,15 @@ __device__ __forceinline__ void answer_request(const PhotonMapView& pm, const Ph
 {
     const int lane = lane_id();
     const Prof pf{nullptr};
-    const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, gp.front_cap, pf, &nb);
-    __builtin_amdgcn_wave_barrier();
     double rgb[3];
-    float md2;
-    estimate_raw(pm, count, r.normal, r.color, gp.norm, rgb, &md2);
+    if (r.flags & GATHER_SURFACE_DONE) {
+        rgb[0] = r.normal[0]; rgb[1] = r.normal[1]; rgb[2] = r.normal[2];
+    } else {
+        const int count = knn_collect(pm, (float)r.pos[0], (float)r.pos[1], (float)r.pos[2], gp.k, gp.r2, gp.front_cap, pf, &nb);
+        __builtin_amdgcn_wave_barrier();
+        float md2;
+        estimate_raw(pm, count, r.normal, r.color, gp.norm, rgb, &md2);
+    }
     if ((r.flags & GATHER_SSS) && vm.n > 0) {                       // main.cpp:297-388
         const float hp[3] = {(float)r.pos[0], (float)r.pos[1], (float)r.pos[2]};
         double sss[3] = {0, 0, 0};

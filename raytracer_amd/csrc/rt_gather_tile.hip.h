@@ -77,6 +77,8 @@ struct TileArgs {
     unsigned long long* n_redo;
     unsigned long long* windows_done;   // [0] windows finished, their hand-overs written; [1] waves of this kernel that have begun (the per-query kernel that runs alongside goes by both)
     int all_redo;                    // nonzero: hand every request to the per-query kernel (comparison runs)
+    int sss_surface;                 // nonzero: form the surface estimate of subsurface requests here and hand the rest on (the per-request
+                                     // kernel must then run AFTER this one: the result travels in the request's record)
     unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
 };
 enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_N_HIST, TP_N_CRIT, TP_N_SUM,
@@ -488,7 +490,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         const GatherRec& r = ta.recs[slot0 + (have ? lane : 0)];
         const float qx = (float)r.pos[0], qy = (float)r.pos[1], qz = (float)r.pos[2];
         const uint32_t flags = r.flags & 0xFFu;
-        bool redo = have && (flags != 0 || ta.all_redo || pm.n >= (1ll << 24));
+        // Subsurface requests: their surface estimate is one of four gathers (main.cpp:260-388) and the only one in this
+        // map; it is formed here with the group's, written into the record, and the request handed on for the rest.
+        const bool sss = (flags & GATHER_SSS) != 0;
+        bool redo = have && ((flags & ~(GATHER_SSS | GATHER_MARCH)) != 0 || (sss && !ta.sss_surface) || ta.all_redo || pm.n >= (1ll << 24));
         bool todo = have && !redo;
         pr[TP_WINDOWS]++;
 #define TILE_COUNT(slot, cond) do { if (ta.prof) pr[slot] += __builtin_popcountll(__ballot(cond)); } while (0)
@@ -662,8 +667,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
             if (summed) {
                 const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
                 double rgb[3] = {r.color[0] * sum.s0 * sc, r.color[1] * sum.s1 * sc, r.color[2] * sum.s2 * sc};
-                clip3(rgb);                                        // main.cpp:391
-                for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
+                if (sss) {
+                    GatherRec* const w = const_cast<GatherRec*>(&r);
+                    w->normal[0] = rgb[0]; w->normal[1] = rgb[1]; w->normal[2] = rgb[2];
+                    w->flags = r.flags | GATHER_SURFACE_DONE;
+                    redo = true;
+                } else {
+                    clip3(rgb);                                    // main.cpp:391
+                    for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }

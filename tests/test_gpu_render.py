@@ -295,6 +295,32 @@ def test_render_subsurface(gpu_ctx):
     assert within >= 0.99 and rmse <= 1.0
 
 
+def test_subsurface_surface_term_in_groups_equals_per_request(gpu_ctx, monkeypatch):
+    """The group gather forms the surface estimate of subsurface requests and hands them on for their volume terms; with
+    every gather answered per request the frame is the same to the rounding of the float partial sums."""
+    g = golden("render_sss_64.npz")
+    s = build_scene(rt.Scene(), "teapot_normal.obj", tuple(g["rgbs"]), float(g["ior"]), (0, -0.7, 0))
+    s.emit_photons(20000, seed=12345)
+    gpu_ctx.upload(s)
+    gpu_ctx.photons_upload(s.photons_get(0))
+    gpu_ctx.photons_upload(s.photons_get(1), which=1)
+    try:
+        cam = rt.look_at(CAM[:3], CAM[3:])
+        for quirk in (0, 1):
+            p = rt.default_params(width=160, height=120, head_quirk=quirk, photon_use=200)
+            grouped, _, st_g = gpu_ctx.render(cam, p)
+            monkeypatch.setenv("RT_GATHER_MODE", "query")
+            single, _, st_q = gpu_ctx.render(cam, p)
+            monkeypatch.delenv("RT_GATHER_MODE")
+            assert st_g.gather_queries == st_q.gather_queries > 5000
+            assert grouped.max() > 0.05
+            err = np.abs(grouped - single).max()
+            print(f"subsurface, grouped surface term vs per request (head_quirk {quirk}): max abs difference {err:.3e}, {st_g.gather_single} of {st_g.gather_queries} requests one per wave")
+            assert err < 2e-6 * max(1.0, np.abs(single).max())
+    finally:
+        gpu_ctx.photons_upload(np.zeros((0, 9)), which=1)
+
+
 def _glossy_scene(api):
     api.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0, -0.7, 0))
     api.add_sphere((0.0, 0.35, 0.55), 0.3, (1.0, 1.0, 1.0, 0.987654), 1.0)      # glossy mirror (main.cpp:640)
