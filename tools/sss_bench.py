@@ -11,7 +11,7 @@ s = rt.Scene()
 s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.9, 0.7, 0.6, -1.0), 1.3, (0, -0.7, 0))
 s.add_cornell(); s.build_bvh()
 ctx = rt.Context(0); ctx.upload(s)
-n_emit = 200000
+n_emit = int(os.environ.get("SSS_EMIT", "200000"))
 (ns, nv), est = ctx.emit_photon_maps(n_emit, seed=12345)
 print(f"photons: {ns} surface, {nv} volume")
 cam = rt.look_at((2.8, 0, 0), (0, 0, 0))
