@@ -202,19 +202,23 @@ def test_render_textures_spheres_and_aa(gpu_ctx):
         assert st.primary_rays == w * h * aa
 
 
-def test_row_bands_and_interleave_compose_the_frame(gpu_ctx):
+@pytest.mark.parametrize("aadepth", [1, 2, 4])
+def test_row_bands_and_interleave_compose_the_frame(gpu_ctx, aadepth):
+    """Blocks of rows, and the bands of rows a rank of several renders, compose the frame -- also with the sample
+    columns of anti-aliasing, which the waves of a tile share among themselves in another way per `aadepth`."""
     s = build_scene(rt.Scene(), "teapot_normal.obj", (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
     s.emit_photons(2000, seed=1)
     gpu_ctx.upload(s); gpu_ctx.photons_upload(s.photons_get())
     cam = rt.look_at(CAM[:3], CAM[3:])
     w, h = 64, 48
-    full, full8, _ = gpu_ctx.render(cam, rt.default_params(width=w, height=h))
-    top, _, _ = gpu_ctx.render(cam, rt.default_params(width=w, height=h), rows=(0, 20))
-    bot, _, _ = gpu_ctx.render(cam, rt.default_params(width=w, height=h), rows=(20, 48))
+    kw = dict(width=w, height=h, aadepth=aadepth)
+    full, full8, _ = gpu_ctx.render(cam, rt.default_params(**kw))
+    top, _, _ = gpu_ctx.render(cam, rt.default_params(**kw), rows=(0, 20))
+    bot, _, _ = gpu_ctx.render(cam, rt.default_params(**kw), rows=(20, 48))
     # (another split of the rows groups the gather requests differently; a group adds four photons' terms in float
     # before they join its double sum, so the frames agree to float rounding of a term, not to the last bit)
     assert np.abs(np.concatenate([top, bot]) - full).max() < 5e-7
-    parts = [gpu_ctx.render(cam, rt.default_params(width=w, height=h, band_rows=8, n_parts=3, part=r))[0] for r in range(3)]
+    parts = [gpu_ctx.render(cam, rt.default_params(band_rows=8, n_parts=3, part=r, **kw))[0] for r in range(3)]
     stacked = np.stack([p.reshape(h // 24, 8, w, 3) for p in parts], axis=1).reshape(h, w, 3)
     assert np.abs(stacked - full).max() < 5e-7
 
