@@ -139,11 +139,15 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
     // so they share its nodes and triangles in L1); the dispatcher balances the load
     int tx, ty, aax;
     if (rtk::tile_of_wave<MODE == rtk::TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, (unsigned)a.aadepth, &aax)) {
-        // The aadepth waves of a tile share its samples.  With 2 or 4 sample columns a wave takes ALL columns of a part of
-        // the tile -- 8 x 4 pixels x 2 or 4 x 4 pixels x 4 -- instead of one column of the whole tile: the columns of a
-        // pixel are almost the same ray, so the wave's rays stay together for longer.
+        // The aadepth waves of a tile share its samples.  With 2, 4 or 8 sample columns a wave takes ALL columns of a part
+        // of the tile -- 8 x 4 pixels x 2, 4 x 4 pixels x 4 or a row of 8 pixels x 8 -- instead of one column of the whole
+        // tile: the columns of a pixel are almost the same ray, so the wave's rays stay together for longer.
         int lx = st.lane & 7, ly = st.lane >> 3;
-        if (a.aadepth == 4) {
+        if (a.aadepth == 8) {
+            const int part = aax;
+            aax = st.lane & 7;
+            lx = st.lane >> 3; ly = part;
+        } else if (a.aadepth == 4) {
             const int part = aax, px = st.lane >> 2;
             aax = st.lane & 3;
             lx = (part & 1) * 4 + (px & 3); ly = (part >> 1) * 4 + (px >> 2);

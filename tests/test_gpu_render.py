@@ -193,7 +193,7 @@ def test_render_textures_spheres_and_aa(gpu_ctx):
     orc.photons_set(np.c_[ph, np.zeros(len(ph))]); orc.build_kdtree()
     gpu_ctx.upload(s); gpu_ctx.photons_upload(ph)
     cam = rt.look_at(CAM[:3], CAM[3:])
-    for aa in (1, 2, 3, 4):
+    for aa in (1, 2, 3, 4, 8):
         w, h = 80, 60
         p = rt.default_params(width=w, height=h, aadepth=aa)
         rgb, bgr, st = gpu_ctx.render(cam, p)
@@ -202,7 +202,7 @@ def test_render_textures_spheres_and_aa(gpu_ctx):
         assert st.primary_rays == w * h * aa
 
 
-@pytest.mark.parametrize("aadepth", [1, 2, 4])
+@pytest.mark.parametrize("aadepth", [1, 2, 4, 8])
 def test_row_bands_and_interleave_compose_the_frame(gpu_ctx, aadepth):
     """Blocks of rows, and the bands of rows a rank of several renders, compose the frame -- also with the sample
     columns of anti-aliasing, which the waves of a tile share among themselves in another way per `aadepth`."""
