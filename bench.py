@@ -5,7 +5,8 @@
         bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the path over one frame: primary rays generated on the device, closest-hit
-BVH traversal, one shadow (occlusion) ray per hit, and -- for N > 1 -- the gather of the row-tiled
+BVH traversal, one shadow ray per hit (an occlusion query over the segment between hit point and light, walked from
+the light and ended at the first occluder), and -- for N > 1 -- the gather of the row-tiled
 hit buffers to rank 0 over RCCL.  Workload at N = 1: teapot1.obj (992 triangles, the mesh the second
 configuration of BASELINE.json names) in the Cornell box (10), camera of the reference's main.cpp,
 1920x1080.  For N > 1 the frame grows by sqrt(N) in each dimension (weak scaling: constant rays per
@@ -533,14 +534,15 @@ def config5(rt, ctx, torch, dev, n_side=100):
 
 
 def _shadow_rays(org, d, ids, t):
-    """Occlusion queries toward the light for the hit pixels, as the device kernel forms them."""
+    """Occlusion queries between the hit points and the light, as the device kernel forms them: the segment from
+    P + L * 1e-4 to the light, walked from the light."""
     light = np.array([0.1, 0.2, 0.0])
     hit = ids >= 0
     P = org[hit] + d[hit] * t[hit][:, None]
     Lv = light - P
     ln = np.sqrt(Lv[:, 0] * Lv[:, 0] + Lv[:, 1] * Lv[:, 1] + Lv[:, 2] * Lv[:, 2])
     L = Lv / ln[:, None]
-    return P + L * 1e-4, L, ln - 1e-4
+    return np.broadcast_to(light, L.shape).copy(), -L, ln - 1e-4
 
 
 def _time_cpu(shoot, org, d, seconds, w, h):

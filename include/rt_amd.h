@@ -69,7 +69,8 @@ typedef struct rt_render_params {
     int32_t precision;        /* rt_precision of traversal + shading                             */
     int32_t shadow_rays;      /* extension (not in the reference): 1 = one occlusion ray per primary hit toward light_pos, the occluder's id (-1: lit, -2: no
                                * primary hit) written to d_shadow_ids; 2 = the same ray, and with d_shadow_ids NULL an occluded hit gets bit 30 set in its d_ids entry
-                               * (one word per pixel to move between GPUs) */
+                               * (one word per pixel to move between GPUs).  That form is an occlusion query over the same segment, walked FROM the light
+                               * (origin light_pos, direction -L, the same range) and ended at the first occluder */
     int32_t count_work;       /* 1: also count inner-node visits and primitive tests (slower instrumented kernel) */
     /* Row interleave for multi-GPU tiling: with band_rows > 0 the call covers only the bands
      * b with b % n_parts == part (band b = image rows [b*band_rows, (b+1)*band_rows)); row_begin /

@@ -473,8 +473,15 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
                     R o2[3] = {(R)so.x, (R)so.y, (R)so.z};
                     R d2[3] = {(R)L.x, (R)L.y, (R)L.z};
                     R range = (R)(len - 1e-4);
-                    // (the folded form reports occlusion only: the walk may stop at the first occluder)
-                    sid = trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o2, d2, range, st, &overflow, &wc, a.shadow == 2 && !shadow_ids);
+                    // (the folded form reports occlusion only: the walk may stop at the first occluder, and it may run either way)
+                    const bool any = a.shadow == 2 && !shadow_ids;
+                    if (any) {
+                        // the same segment walked from the light: the rays of a tile then leave one point side by side, like its
+                        // camera rays, and meet what stands near the light -- where the occluders of most pixels are -- first
+                        o2[0] = (R)a.light[0]; o2[1] = (R)a.light[1]; o2[2] = (R)a.light[2];
+                        d2[0] = (R)(-L.x); d2[1] = (R)(-L.y); d2[2] = (R)(-L.z);
+                    }
+                    sid = trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o2, d2, range, st, &overflow, &wc, any);
                     n_shadow++;
                 }
                 if (shadow_ids) shadow_ids[px] = sid;

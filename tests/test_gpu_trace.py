@@ -229,7 +229,9 @@ def test_shadow_rays_match_oracle(gpu_ctx, scenes):
 @pytest.mark.parametrize("precision", [rt.RT_F64, rt.RT_F32])
 def test_folded_shadow_bit_is_the_occlusion_of_the_shadow_ids(gpu_ctx, scenes, scene, precision):
     """shadow_rays = 2 without a shadow-id buffer: one word per pixel, bit 30 set where the shadow ray is occluded.  That
-    walk may stop at the first occluder; its answer is `shadow id >= 0` of the full walk, pixel for pixel."""
+    query stops at the first occluder and walks the segment from the light; its answer is `shadow id >= 0` of the full
+    walk from the surface except where rounding decides (a ray grazing an edge), and exactly the CPU oracle's Shoot on
+    the same query (origin the light, direction -L, range |light - P| - 1e-4)."""
     import ctypes
     gpu_ctx.upload(scenes[scene])
     w, h = 640, 360
@@ -246,8 +248,27 @@ def test_folded_shadow_bit_is_the_occlusion_of_the_shadow_ids(gpu_ctx, scenes, s
     bit = 1 << 30
     assert eq(np.where(folded >= 0, folded & ~bit, folded), ids)
     occluded = (folded >= 0) & ((folded & bit) != 0)
-    assert eq(occluded, sh >= 0) and 0.02 < occluded.mean() < 0.9
+    differ = float((occluded != (sh >= 0)).mean())
+    assert differ < 1e-4 and 0.02 < occluded.mean() < 0.9, differ
     assert st2.shadow_rays == st1.shadow_rays
+    # the query itself, against the oracle (the float instantiation against the single-precision restatement)
+    orc = build_scene(Oracle(), scene + ".obj")
+    org, d = orc.primary_rays(w, h, CAM)
+    oid, ot = orc.shoot(org, d)
+    if precision == rt.RT_F32:
+        oid, ot = orc.shoot_f32(org, d)
+    assert eq(oid, ids)
+    hit = oid >= 0
+    P = org[hit] + d[hit] * ot[hit][:, None]
+    Lv = light - P
+    ln = np.sqrt(Lv[:, 0] * Lv[:, 0] + Lv[:, 1] * Lv[:, 1] + Lv[:, 2] * Lv[:, 2])
+    L = Lv / ln[:, None]
+    from_light = np.broadcast_to(light, L.shape).copy()
+    shoot = orc.shoot_f32 if precision == rt.RT_F32 else orc.shoot
+    sid, _ = shoot(from_light, -L, ln - 1e-4)
+    exp = np.zeros(w * h, bool)
+    exp[hit] = sid >= 0
+    assert eq(occluded, exp)
 
 
 def test_mixed_primitives_and_planes(gpu_ctx):
