@@ -409,6 +409,8 @@ def strong_scaling_leg(rt, ctx, torch, dist, dev, world, rank, ext, what, build,
         done = torch.cuda.Event(); done.record(ext)
         torch.cuda.current_stream().wait_event(done)
         tiling.gather_to_rank0(part, world, rank, dist, recv)
+        read = torch.cuda.Event(); read.record()
+        ext.wait_event(read)                             # the next frame overwrites `part` only after this gather has read it
     sync()
     dt = torch.tensor([(_time.perf_counter() - t0) / reps], dtype=torch.float64, device=dev)
     if world > 1:
