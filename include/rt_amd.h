@@ -188,6 +188,24 @@ int rt_scene_upload(rt_context* ctx, const rt_scene* s);
  * of the build. */
 int rt_scene_upload_lbvh(rt_context* ctx, const rt_scene* s, double* build_ms);
 
+/* A built scene as one block of bytes, and back.  The reference builds its tree once, before its render threads fan
+ * out over the image (main.cpp:678, 735); with one process per GPU the process that built the tree hands the others
+ * this image instead of each parsing the meshes and building the same tree again.  The image holds the per-object
+ * shading records, the inner nodes, the leaf-ordered primitive records, the plane list, texture descriptors and
+ * texels as plain records behind a header with a magic word, a version and the record sizes; it contains no
+ * pointers and may be sent between processes of the same build as it is (photons are not part of it).
+ *   rt_scene_export_flat: buf NULL -> *bytes = size needed; otherwise writes the image (buf 64-byte aligned, *bytes
+ *                         its capacity on entry, the image's size on return).  The tree must have been built.
+ *   rt_scene_import_flat: replaces the contents of `s` by the image's scene, tree included (rt_scene_bvh_dump,
+ *                         rt_scene_upload, photon emission then work as on the scene that was exported).
+ *   rt_scene_upload_flat: rt_scene_upload straight from an image, without an rt_scene in between.
+ * Both readers check the image before they trust it -- sizes, section bounds, every child, primitive, object and
+ * texture index, and that inner children follow their parent (no cycle) -- and return RT_ERR_INVALID with the reason
+ * otherwise; buf must be 64-byte aligned. */
+int rt_scene_export_flat(const rt_scene* s, void* buf, size_t* bytes);
+int rt_scene_import_flat(rt_scene* s, const void* buf, size_t bytes);
+int rt_scene_upload_flat(rt_context* ctx, const void* buf, size_t bytes);
+
 /* BVH::Shoot(ray, dist) for a batch, BVH.cpp:108.  org/dir: n x 3 doubles; dist: in = max range
  * (the reference's in/out `distance`), out = hit distance (unchanged on a miss); ids: object id or -1.
  * Host buffers (copied through PCIe, not the measured path). */

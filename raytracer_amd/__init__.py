@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import RT_F32, RT_F64, Camera, RenderParams, Stats, lib
 
-__all__ = ["Scene", "Context", "RtError", "RT_F32", "RT_F64", "default_params", "look_at", "save_bmp", "gather_rows"]
+__all__ = ["Scene", "Context", "RtError", "RT_F32", "RT_F64", "default_params", "look_at", "save_bmp", "gather_rows", "aligned_bytes"]
 
 
 class RtError(RuntimeError):
@@ -50,6 +50,23 @@ def look_at(pos=(2.8, 0, 0), target=(0, 0, 0)):
     cam = Camera()
     lib.rt_camera_look_at(_dp(_f64(pos)), _dp(_f64(target)), ctypes.byref(cam))
     return cam
+
+
+def aligned_bytes(n, align=64):
+    """A writable uint8 array of n bytes whose first byte sits at a multiple of `align` (flat scene images need 64)."""
+    raw = np.empty(n + align, np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n]
+
+
+def _as_image(buf):
+    """uint8 view of a flat scene image at a 64-byte aligned address (copied only when it is not there already)."""
+    a = np.ascontiguousarray(np.asarray(buf).view(np.uint8).ravel())
+    if a.ctypes.data % 64:
+        b = aligned_bytes(a.size)
+        b[:] = a
+        a = b
+    return a
 
 
 class Scene:
@@ -131,6 +148,19 @@ class Scene:
     def bvh_depth(self):
         return lib.rt_scene_bvh_depth(self.h)
 
+    def export_flat(self):
+        """The built scene as one block of bytes (uint8 array, 64-byte aligned): rt_scene_export_flat."""
+        n = ctypes.c_size_t(0)
+        _chk(lib.rt_scene_export_flat(self.h, None, ctypes.byref(n)), "rt_scene_export_flat")
+        buf = aligned_bytes(n.value)
+        _chk(lib.rt_scene_export_flat(self.h, buf.ctypes.data, ctypes.byref(n)), "rt_scene_export_flat")
+        return buf
+
+    def import_flat(self, image):
+        """Replace this scene by the one in a flat image: rt_scene_import_flat."""
+        a = _as_image(image)
+        _chk(lib.rt_scene_import_flat(self.h, a.ctypes.data, a.size), "rt_scene_import_flat")
+
     def bvh_dump(self):
         n_rec = ctypes.c_int64(0)
         n_box = ctypes.c_int64(0)
@@ -165,6 +195,11 @@ class Context:
 
     def upload(self, scene):
         _chk(lib.rt_scene_upload(self.h, scene.h), "rt_scene_upload")
+
+    def upload_flat(self, image):
+        """rt_scene_upload from a flat image (Scene.export_flat of this or another process)."""
+        a = _as_image(image)
+        _chk(lib.rt_scene_upload_flat(self.h, a.ctypes.data, a.size), "rt_scene_upload_flat")
 
     def upload_lbvh(self, scene):
         """Upload with the tree built on the GPU (linear BVH, not the reference's tree); returns the build's device ms."""

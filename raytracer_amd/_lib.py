@@ -80,6 +80,9 @@ PROTOTYPES = {
     "rt_scene_photons_clear": (None, [vp]),
     "rt_scene_upload": (c_i, [vp, vp]),
     "rt_scene_upload_lbvh": (c_i, [vp, vp, P(c_d)]),
+    "rt_scene_export_flat": (c_i, [vp, vp, P(ctypes.c_size_t)]),
+    "rt_scene_import_flat": (c_i, [vp, vp, ctypes.c_size_t]),
+    "rt_scene_upload_flat": (c_i, [vp, vp, ctypes.c_size_t]),
     "rt_trace_closest": (c_i, [vp, c_i, c_i64, P(c_d), P(c_d), P(c_d), P(c_i32)]),
     "rt_trace_closest_dev": (c_i, [vp, c_i, c_i64, vp, vp, vp, vp]),
     "rt_trace_primary_dev": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, vp, vp, vp, P(Stats)]),

@@ -446,10 +446,10 @@ void Scene::bvh_dump(std::vector<int32_t>& rec, std::vector<double>& boxes) cons
     }
 }
 
-std::vector<rtf::Node<float>> to_f32(const std::vector<rtf::Node<double>>& n)
+std::vector<rtf::Node<float>> to_f32(const rtf::Node<double>* n, size_t count)
 {
-    std::vector<rtf::Node<float>> o(n.size());
-    for (size_t k = 0; k < n.size(); k++) {
+    std::vector<rtf::Node<float>> o(count);
+    for (size_t k = 0; k < count; k++) {
         for (int i = 0; i < 3; i++) {
             o[k].lo0[i] = (float)n[k].lo0[i]; o[k].hi0[i] = (float)n[k].hi0[i];
             o[k].lo1[i] = (float)n[k].lo1[i]; o[k].hi1[i] = (float)n[k].hi1[i];
@@ -460,15 +460,185 @@ std::vector<rtf::Node<float>> to_f32(const std::vector<rtf::Node<double>>& n)
     return o;
 }
 
-std::vector<rtf::Prim<float>> to_f32(const std::vector<rtf::Prim<double>>& p)
+std::vector<rtf::Prim<float>> to_f32(const rtf::Prim<double>* p, size_t count)
 {
-    std::vector<rtf::Prim<float>> o(p.size());
-    for (size_t k = 0; k < p.size(); k++) {
+    std::vector<rtf::Prim<float>> o(count);
+    for (size_t k = 0; k < count; k++) {
         for (int i = 0; i < 3; i++) { o[k].a[i] = (float)p[k].a[i]; o[k].e1[i] = (float)p[k].e1[i]; o[k].e2[i] = (float)p[k].e2[i]; }
         o[k].id = p[k].id;
         o[k].kind = p[k].kind;
     }
     return o;
+}
+
+// ---------------------------------------------------------------- flat image of a built scene
+namespace {
+inline size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+// section offsets for the counts in h (fills off_* and total_bytes)
+void flat_layout(FlatImageHeader& h)
+{
+    size_t at = sizeof(FlatImageHeader);
+    auto take = [&](size_t bytes) { size_t o = at; at = up64(at + bytes); return (uint64_t)o; };
+    h.off_objects = take(h.n_objects * sizeof(rtf::ObjShade));
+    h.off_has_uv = take(h.n_objects);
+    h.off_nodes = take(h.n_nodes * sizeof(rtf::Node<double>));
+    h.off_prims = take(h.n_prims * sizeof(rtf::Prim<double>));
+    h.off_planes = take(h.n_planes * sizeof(rtf::Prim<double>));
+    h.off_texdesc = take(h.n_textures * sizeof(rtf::TexDesc));
+    h.off_texels = take(h.n_texel_doubles * sizeof(double));
+    h.total_bytes = at;
+}
+
+FlatImageHeader flat_header(const Scene& s)
+{
+    FlatImageHeader h{};
+    h.magic = FLAT_MAGIC;
+    h.version = FLAT_VERSION;
+    h.sizeof_header = sizeof(FlatImageHeader);
+    h.sizeof_objshade = sizeof(rtf::ObjShade);
+    h.sizeof_node = sizeof(rtf::Node<double>);
+    h.sizeof_prim = sizeof(rtf::Prim<double>);
+    h.n_objects = s.objects.size();
+    h.n_nodes = s.bvh.nodes.size();
+    h.n_prims = s.bvh.prims.size();
+    h.n_planes = s.bvh.planes.size();
+    h.n_textures = s.textures.size();
+    for (const Texture& t : s.textures) h.n_texel_doubles += t.rgb.size();
+    for (int i = 0; i < 3; i++) { h.root_lo[i] = s.bvh.root_box.lo[i]; h.root_hi[i] = s.bvh.root_box.hi[i]; }
+    h.root_ref = s.bvh.root_ref;
+    h.depth = s.bvh.depth;
+    h.n_leaves = s.bvh.n_leaves;
+    flat_layout(h);
+    return h;
+}
+}  // namespace
+
+size_t flat_image_bytes(const Scene& s) { return (size_t)flat_header(s).total_bytes; }
+
+void flat_image_write(const Scene& s, void* out)
+{
+    const FlatImageHeader h = flat_header(s);
+    char* b = (char*)out;
+    memset(b, 0, (size_t)h.total_bytes);      // (padding between sections is defined: two images of one scene compare equal)
+    memcpy(b, &h, sizeof h);
+    rtf::ObjShade* o = (rtf::ObjShade*)(b + h.off_objects);
+    uint8_t* uv = (uint8_t*)(b + h.off_has_uv);
+    for (size_t i = 0; i < s.objects.size(); i++) { memcpy(&o[i], &s.objects[i].sh, sizeof(rtf::ObjShade)); uv[i] = s.objects[i].has_uv ? 1 : 0; }
+    if (h.n_nodes) memcpy(b + h.off_nodes, s.bvh.nodes.data(), h.n_nodes * sizeof(rtf::Node<double>));
+    if (h.n_prims) memcpy(b + h.off_prims, s.bvh.prims.data(), h.n_prims * sizeof(rtf::Prim<double>));
+    if (h.n_planes) memcpy(b + h.off_planes, s.bvh.planes.data(), h.n_planes * sizeof(rtf::Prim<double>));
+    rtf::TexDesc* td = (rtf::TexDesc*)(b + h.off_texdesc);
+    double* tx = (double*)(b + h.off_texels);
+    int64_t at = 0;
+    for (size_t i = 0; i < s.textures.size(); i++) {
+        td[i] = rtf::TexDesc{s.textures[i].x_res, s.textures[i].y_res, at};
+        if (!s.textures[i].rgb.empty()) memcpy(tx + at, s.textures[i].rgb.data(), s.textures[i].rgb.size() * sizeof(double));
+        at += (int64_t)s.textures[i].rgb.size();
+    }
+}
+
+int flat_image_open(const void* buf, size_t bytes, FlatImageView* v, std::string* err)
+{
+    auto bad = [&](const char* why) { if (err) *err = why; return -1; };
+    if (!buf || bytes < sizeof(FlatImageHeader)) return bad("flat scene image: shorter than its header");
+    if ((uintptr_t)buf % 64 != 0) return bad("flat scene image: the buffer is not 64-byte aligned");
+    FlatImageHeader h;
+    memcpy(&h, buf, sizeof h);
+    if (h.magic != FLAT_MAGIC) return bad("flat scene image: wrong magic word");
+    if (h.version != FLAT_VERSION) return bad("flat scene image: unknown version");
+    if (h.sizeof_header != sizeof(FlatImageHeader) || h.sizeof_objshade != sizeof(rtf::ObjShade) || h.sizeof_node != sizeof(rtf::Node<double>) ||
+        h.sizeof_prim != sizeof(rtf::Prim<double>))
+        return bad("flat scene image: record sizes differ from this build's");
+    const uint64_t lim = 1ull << 40;
+    if (h.n_objects >= (1ull << 31) || h.n_nodes >= (1ull << 31) || h.n_prims >= (1ull << rtf::LEAF_COUNT_SHIFT) || h.n_planes >= (1ull << 31) ||
+        h.n_textures >= (1ull << 20) || h.n_texel_doubles >= lim)
+        return bad("flat scene image: a count is out of range");
+    FlatImageHeader want = h;
+    flat_layout(want);
+    if (want.total_bytes != h.total_bytes || want.off_objects != h.off_objects || want.off_has_uv != h.off_has_uv || want.off_nodes != h.off_nodes ||
+        want.off_prims != h.off_prims || want.off_planes != h.off_planes || want.off_texdesc != h.off_texdesc || want.off_texels != h.off_texels)
+        return bad("flat scene image: section offsets do not match the counts");
+    if (h.total_bytes > bytes) return bad("flat scene image: truncated");
+    const char* b = (const char*)buf;
+    FlatImageView w;
+    w.h = (const FlatImageHeader*)b;
+    w.objects = (const rtf::ObjShade*)(b + h.off_objects);
+    w.has_uv = (const uint8_t*)(b + h.off_has_uv);
+    w.nodes = (const rtf::Node<double>*)(b + h.off_nodes);
+    w.prims = (const rtf::Prim<double>*)(b + h.off_prims);
+    w.planes = (const rtf::Prim<double>*)(b + h.off_planes);
+    w.texdesc = (const rtf::TexDesc*)(b + h.off_texdesc);
+    w.texels = (const double*)(b + h.off_texels);
+    // textures, then the objects that name them
+    for (uint64_t i = 0; i < h.n_textures; i++) {
+        const rtf::TexDesc& t = w.texdesc[i];
+        if (t.x_res <= 0 || t.y_res <= 0 || t.offset < 0 || (uint64_t)t.offset + 3ull * (uint64_t)t.x_res * (uint64_t)t.y_res > h.n_texel_doubles)
+            return bad("flat scene image: a texture lies outside the texel pool");
+    }
+    for (uint64_t i = 0; i < h.n_objects; i++) {
+        const rtf::ObjShade& o = w.objects[i];
+        if (o.kind > rtf::PRIM_PLANE) return bad("flat scene image: unknown object kind");
+        if (o.has_texture && (o.map < 0 || (uint64_t)o.map >= h.n_textures)) return bad("flat scene image: an object names a texture that is not there");
+    }
+    for (uint64_t i = 0; i < h.n_prims; i++)
+        if (w.prims[i].id >= h.n_objects || w.prims[i].kind > rtf::PRIM_SPHERE) return bad("flat scene image: a primitive record names no object");
+    for (uint64_t i = 0; i < h.n_planes; i++)
+        if (w.planes[i].id >= h.n_objects || w.planes[i].kind != rtf::PRIM_PLANE) return bad("flat scene image: a plane record names no object");
+    // the tree: leaves inside the primitive array, inner children behind their parent (pre-order, hence no cycle)
+    auto leaf_ok = [&](uint32_t ref) {
+        const uint64_t first = ref & rtf::LEAF_FIRST_MASK, cnt = (ref >> rtf::LEAF_COUNT_SHIFT) & 15;
+        return cnt >= 1 && first + cnt <= h.n_prims;
+    };
+    if (h.root_ref == rtf::NO_NODE) {
+        if (h.n_nodes || h.n_prims) return bad("flat scene image: nodes without a root");
+    } else if (h.root_ref & rtf::LEAF_BIT) {
+        if (h.n_nodes || !leaf_ok(h.root_ref)) return bad("flat scene image: bad root leaf");
+        w.n_leaves = 1;
+    } else {
+        if (h.root_ref != 0 || h.n_nodes == 0) return bad("flat scene image: the root is not node 0");
+        std::vector<int32_t> level(h.n_nodes, -1);
+        level[0] = 0;
+        for (uint64_t i = 0; i < h.n_nodes; i++) {
+            if (level[i] < 0) return bad("flat scene image: a node no parent refers to");
+            for (uint32_t c : {w.nodes[i].c0, w.nodes[i].c1}) {
+                if (c & rtf::LEAF_BIT) {
+                    if (!leaf_ok(c)) return bad("flat scene image: a leaf lies outside the primitive array");
+                    w.n_leaves++;
+                    w.depth = std::max(w.depth, level[i] + 1);
+                } else {
+                    if (c <= i || c >= h.n_nodes || level[c] >= 0) return bad("flat scene image: a child reference breaks the pre-order");
+                    level[c] = level[i] + 1;
+                    w.depth = std::max(w.depth, level[c]);
+                }
+            }
+        }
+    }
+    *v = w;
+    return 0;
+}
+
+void flat_image_read(const FlatImageView& v, Scene& s)
+{
+    const FlatImageHeader& h = *v.h;
+    s = Scene{};
+    s.objects.resize(h.n_objects);
+    for (uint64_t i = 0; i < h.n_objects; i++) { s.objects[i].sh = v.objects[i]; s.objects[i].has_uv = v.has_uv[i] != 0; }
+    s.textures.resize(h.n_textures);
+    for (uint64_t i = 0; i < h.n_textures; i++) {
+        Texture& t = s.textures[i];
+        t.x_res = v.texdesc[i].x_res; t.y_res = v.texdesc[i].y_res;
+        const double* from = v.texels + v.texdesc[i].offset;
+        t.rgb.assign(from, from + (size_t)3 * t.x_res * t.y_res);
+    }
+    s.bvh.nodes.assign(v.nodes, v.nodes + h.n_nodes);
+    s.bvh.prims.assign(v.prims, v.prims + h.n_prims);
+    s.bvh.planes.assign(v.planes, v.planes + h.n_planes);
+    for (int i = 0; i < 3; i++) { s.bvh.root_box.lo[i] = h.root_lo[i]; s.bvh.root_box.hi[i] = h.root_hi[i]; }
+    s.bvh.root_ref = h.root_ref;
+    s.bvh.depth = v.depth;
+    s.bvh.n_leaves = v.n_leaves;
+    s.bvh.built = true;
 }
 
 // ---------------------------------------------------------------- BMP writer (IO.cpp:5-68)

@@ -90,6 +90,15 @@ int upload(DevBuf& b, const std::vector<T>& v, hipStream_t s)
     return RT_OK;
 }
 
+template <class T>
+int upload_n(DevBuf& b, const T* v, size_t n, hipStream_t s)
+{
+    int rc = b.reserve(std::max<size_t>(n * sizeof(T), 64));
+    if (rc) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(b.p, v, n * sizeof(T), hipMemcpyHostToDevice, s));
+    return RT_OK;
+}
+
 }  // namespace
 
 // ---- working memory of the entry point that allocates nothing (rt_knn_estimate_dev_noalloc) -----------------------
@@ -936,15 +945,13 @@ void rt_scene_photons_clear(rt_scene* s)
 // ---------------------------------------------------------------- device scene
 }  // extern "C"
 namespace {
-// per-object shading records and the texel pool (synchronises: the host copies die at return)
-int upload_shading(rt_context* ctx, const rth::Scene& s)
+// per-object shading records and the texel pool (synchronises: the caller's arrays may die at return)
+int upload_shading(rt_context* ctx, const rtf::ObjShade* sh, size_t n_objects, const rtf::TexDesc* td, size_t n_textures, const double* texels, size_t n_texel_doubles)
 {
     int rc;
-    std::vector<rtf::ObjShade> sh(s.objects.size());
-    std::vector<unsigned char> live(sh.size());
+    std::vector<unsigned char> live(n_objects);
     ctx->has_glossy = ctx->has_bounce = ctx->has_sss = false;
-    for (size_t i = 0; i < sh.size(); i++) {
-        sh[i] = s.objects[i].sh;
+    for (size_t i = 0; i < n_objects; i++) {
         if (sh[i].color[3] != 0.0) ctx->has_bounce = true;
         if (sh[i].color[3] < 0.0) ctx->has_sss = true;
         if (rtm::glossy_special(sh[i].color[3])) ctx->has_glossy = true;
@@ -952,17 +959,70 @@ int upload_shading(rt_context* ctx, const rth::Scene& s)
         const bool textured = sh[i].kind == rtf::PRIM_TRI && sh[i].has_texture && sh[i].map >= 0;
         live[i] = sh[i].color[3] > 0 && !textured ? 1 : 0;
     }
-    if ((rc = upload(ctx->objs, sh, ctx->stream))) return rc;
+    if ((rc = upload_n(ctx->objs, sh, n_objects, ctx->stream))) return rc;
     if ((rc = upload(ctx->obj_live, live, ctx->stream))) return rc;
+    if ((rc = upload_n(ctx->texdesc, td, n_textures, ctx->stream))) return rc;
+    if ((rc = upload_n(ctx->texels, texels, n_texel_doubles, ctx->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RT_OK;
+}
+
+int upload_shading(rt_context* ctx, const rth::Scene& s)
+{
+    std::vector<rtf::ObjShade> sh(s.objects.size());
+    for (size_t i = 0; i < sh.size(); i++) sh[i] = s.objects[i].sh;
     std::vector<rtf::TexDesc> td;
     std::vector<double> pool;
     for (const auto& t : s.textures) {
         td.push_back({t.x_res, t.y_res, (int64_t)pool.size()});
         pool.insert(pool.end(), t.rgb.begin(), t.rgb.end());
     }
-    if ((rc = upload(ctx->texdesc, td, ctx->stream))) return rc;
-    if ((rc = upload(ctx->texels, pool, ctx->stream))) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return upload_shading(ctx, sh.data(), sh.size(), td.data(), td.size(), pool.data(), pool.size());
+}
+
+// The host tree and its primitive records, in both precisions, to HBM; the context's views follow.
+struct HostTree {
+    const rtf::Node<double>* nodes; size_t n_nodes;
+    const rtf::Prim<double>* prims; size_t n_prims;
+    const rtf::Prim<double>* planes; size_t n_planes;
+    double root_lo[3], root_hi[3];
+    uint32_t root_ref;
+    int depth;
+};
+
+int upload_tree(rt_context* ctx, const HostTree& t, size_t n_objects)
+{
+    int rc;
+    auto n32 = rth::to_f32(t.nodes, t.n_nodes);
+    auto p32 = rth::to_f32(t.prims, t.n_prims);
+    auto pl32 = rth::to_f32(t.planes, t.n_planes);
+    if ((rc = upload_n(ctx->nodes64, t.nodes, t.n_nodes, ctx->stream))) return rc;
+    if ((rc = upload_n(ctx->prims64, t.prims, t.n_prims, ctx->stream))) return rc;
+    if ((rc = upload_n(ctx->planes64, t.planes, t.n_planes, ctx->stream))) return rc;
+    if ((rc = upload(ctx->nodes32, n32, ctx->stream))) return rc;
+    if ((rc = upload(ctx->prims32, p32, ctx->stream))) return rc;
+    if ((rc = upload(ctx->planes32, pl32, ctx->stream))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the float copies above die at return
+    ctx->v64.nodes = (const rtf::Node<double>*)ctx->nodes64.p;
+    ctx->v64.prims = (const rtf::Prim<double>*)ctx->prims64.p;
+    ctx->v64.planes = (const rtf::Prim<double>*)ctx->planes64.p;
+    ctx->v32.nodes = (const rtf::Node<float>*)ctx->nodes32.p;
+    ctx->v32.prims = (const rtf::Prim<float>*)ctx->prims32.p;
+    ctx->v32.planes = (const rtf::Prim<float>*)ctx->planes32.p;
+    for (int i = 0; i < 3; i++) {
+        ctx->v64.root_lo[i] = t.root_lo[i]; ctx->v64.root_hi[i] = t.root_hi[i];
+        ctx->v32.root_lo[i] = (float)t.root_lo[i]; ctx->v32.root_hi[i] = (float)t.root_hi[i];
+    }
+    ctx->v64.root_ref = ctx->v32.root_ref = t.root_ref;
+    ctx->v64.n_planes = ctx->v32.n_planes = (int32_t)t.n_planes;
+    bool tri_only = true;
+    for (size_t i = 0; i < t.n_prims; i++) tri_only = tri_only && t.prims[i].kind == rtf::PRIM_TRI;
+    ctx->v64.tri_only = ctx->v32.tri_only = tri_only ? 1 : 0;
+    ctx->depth = t.depth;
+    ctx->n_nodes = (int)t.n_nodes;
+    ctx->n_prims = (int)t.n_prims;
+    ctx->n_objects = (int)n_objects;
+    ctx->has_scene = true;
     return RT_OK;
 }
 }  // namespace
@@ -977,39 +1037,57 @@ int rt_scene_upload(rt_context* ctx, const rt_scene* scene)
     int rc = use_device(ctx);
     if (rc) return rc;
     const rth::FlatBVH& b = s.bvh;
-    auto n32 = rth::to_f32(b.nodes);
-    auto p32 = rth::to_f32(b.prims);
-    auto pl32 = rth::to_f32(b.planes);
-    if ((rc = upload(ctx->nodes64, b.nodes, ctx->stream))) return rc;
-    if ((rc = upload(ctx->prims64, b.prims, ctx->stream))) return rc;
-    if ((rc = upload(ctx->planes64, b.planes, ctx->stream))) return rc;
-    if ((rc = upload(ctx->nodes32, n32, ctx->stream))) return rc;
-    if ((rc = upload(ctx->prims32, p32, ctx->stream))) return rc;
-    if ((rc = upload(ctx->planes32, pl32, ctx->stream))) return rc;
     if ((rc = upload_shading(ctx, s))) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // the host vectors above die at return
+    HostTree t{b.nodes.data(), b.nodes.size(), b.prims.data(), b.prims.size(), b.planes.data(), b.planes.size(), {}, {}, b.root_ref, b.depth};
+    for (int i = 0; i < 3; i++) { t.root_lo[i] = b.root_box.lo[i]; t.root_hi[i] = b.root_box.hi[i]; }
+    return upload_tree(ctx, t, s.objects.size());
+    });
+}
 
-    ctx->v64.nodes = (const rtf::Node<double>*)ctx->nodes64.p;
-    ctx->v64.prims = (const rtf::Prim<double>*)ctx->prims64.p;
-    ctx->v64.planes = (const rtf::Prim<double>*)ctx->planes64.p;
-    ctx->v32.nodes = (const rtf::Node<float>*)ctx->nodes32.p;
-    ctx->v32.prims = (const rtf::Prim<float>*)ctx->prims32.p;
-    ctx->v32.planes = (const rtf::Prim<float>*)ctx->planes32.p;
-    for (int i = 0; i < 3; i++) {
-        ctx->v64.root_lo[i] = b.root_box.lo[i]; ctx->v64.root_hi[i] = b.root_box.hi[i];
-        ctx->v32.root_lo[i] = (float)b.root_box.lo[i]; ctx->v32.root_hi[i] = (float)b.root_box.hi[i];
+int rt_scene_export_flat(const rt_scene* scene, void* buf, size_t* bytes)
+{
+    return guarded([&]() -> int {
+    if (!scene || !bytes) return fail(RT_ERR_INVALID, "null argument");
+    if (!scene->s.bvh.built) return fail(RT_ERR_STATE, "rt_scene_build_bvh has not been called");
+    const size_t need = rth::flat_image_bytes(scene->s);
+    if (buf) {
+        if (*bytes < need) return fail(RT_ERR_INVALID, "buffer of %zu bytes, the image takes %zu", *bytes, need);
+        if ((uintptr_t)buf % 64 != 0) return fail(RT_ERR_INVALID, "the buffer is not 64-byte aligned");
+        rth::flat_image_write(scene->s, buf);
     }
-    ctx->v64.root_ref = ctx->v32.root_ref = b.root_ref;
-    ctx->v64.n_planes = ctx->v32.n_planes = (int32_t)b.planes.size();
-    bool tri_only = true;
-    for (const auto& pr : b.prims) tri_only = tri_only && pr.kind == rtf::PRIM_TRI;
-    ctx->v64.tri_only = ctx->v32.tri_only = tri_only ? 1 : 0;
-    ctx->depth = b.depth;
-    ctx->n_nodes = (int)b.nodes.size();
-    ctx->n_prims = (int)b.prims.size();
-    ctx->n_objects = (int)s.objects.size();
-    ctx->has_scene = true;
+    *bytes = need;
     return RT_OK;
+    });
+}
+
+int rt_scene_import_flat(rt_scene* scene, const void* buf, size_t bytes)
+{
+    return guarded([&]() -> int {
+    if (!scene || !buf) return fail(RT_ERR_INVALID, "null argument");
+    rth::FlatImageView v;
+    std::string why;
+    if (rth::flat_image_open(buf, bytes, &v, &why)) return fail(RT_ERR_INVALID, "%s", why.c_str());
+    rth::flat_image_read(v, scene->s);
+    scene->photons[0].clear();
+    scene->photons[1].clear();
+    return RT_OK;
+    });
+}
+
+int rt_scene_upload_flat(rt_context* ctx, const void* buf, size_t bytes)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !buf) return fail(RT_ERR_INVALID, "null argument");
+    rth::FlatImageView v;
+    std::string why;
+    if (rth::flat_image_open(buf, bytes, &v, &why)) return fail(RT_ERR_INVALID, "%s", why.c_str());
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const rth::FlatImageHeader& h = *v.h;
+    if ((rc = upload_shading(ctx, v.objects, h.n_objects, v.texdesc, h.n_textures, v.texels, h.n_texel_doubles))) return rc;
+    HostTree t{v.nodes, (size_t)h.n_nodes, v.prims, (size_t)h.n_prims, v.planes, (size_t)h.n_planes, {}, {}, h.root_ref, v.depth};
+    for (int i = 0; i < 3; i++) { t.root_lo[i] = h.root_lo[i]; t.root_hi[i] = h.root_hi[i]; }
+    return upload_tree(ctx, t, (size_t)h.n_objects);
     });
 }
 

@@ -59,3 +59,35 @@ def gather_to_rank0(buf, world, rank, dist, out=None):
         out = [torch.empty_like(buf) for _ in range(world)]
     dist.gather(buf, out if rank == 0 else None, dst=0)
     return out if rank == 0 else None
+
+
+def broadcast_scene(build, rank, dist, torch, device=None):
+    """One scene for all ranks, built once: rank 0 calls build() -> a raytracer_amd.Scene with its tree built and
+    broadcasts the flat image of it (rt_scene_export_flat); every rank gets the image back as a uint8 array ready
+    for Scene.import_flat / Context.upload_flat.  The reference builds its tree once before its threads fan out
+    (main.cpp:678, 735); here the other ranks neither parse meshes nor build anything.  `device`: where the
+    collective's tensors live (a CUDA device for the RCCL backend, None for gloo)."""
+    import numpy as np
+
+    from . import aligned_bytes
+    img = None
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == 0:
+        img = build().export_flat()
+        n[0] = img.size
+    dist.broadcast(n, src=0)
+    size = int(n.item())
+    if rank == 0:
+        t = torch.from_numpy(img)
+    else:
+        img = aligned_bytes(size)
+        t = torch.from_numpy(img)
+    if device is not None:
+        d = t.to(device)
+        dist.broadcast(d, src=0)
+        if rank != 0:
+            t.copy_(d)
+        del d
+    else:
+        dist.broadcast(t, src=0)
+    return img

@@ -435,3 +435,56 @@ def test_meshes_without_normals(gpu_ctx, tag):
     rgb, _, _ = gpu_ctx.render(cam, rt.default_params(width=64, height=64))
     a = np.floor(np.clip(rgb, 0, 1) * 255).astype(np.int32); b = np.floor(np.clip(g["rgb64"], 0, 1) * 255).astype(np.int32)
     assert (np.abs(a - b).max(-1) <= 1).mean() >= 0.999 and np.abs(rgb - g["rgb64"]).max() < 2e-3
+
+
+def test_scene_uploaded_from_a_flat_image(gpu_ctx, scenes):
+    """A scene that reaches the device as a flat image (built in another process, rt_scene_export_flat ->
+    rt_scene_upload_flat, or rt_scene_import_flat -> rt_scene_upload) traces the reference's hits: the golden frame,
+    the golden batch rays, and a mixed scene with spheres, a plane and a texture against the oracle."""
+    img = scenes["teapot_normal"].export_flat()
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    h = golden("hits_teapot_normal_96x54.npz")
+    g = golden("rays_teapot_normal.npz")
+
+    def check():
+        ids, t, _, _ = gpu_ctx.trace_primary(cam, rt.default_params(width=96, height=54))
+        assert eq(ids.ravel(), h["ids"].ravel()) and eq(np.where(ids >= 0, t, 1e9).ravel(), h["t"].ravel())
+        ids, t = gpu_ctx.trace_closest(g["org_axis"], g["dir_axis"])
+        assert eq(ids, g["ids_axis"]) and eq(t, g["t_axis"])
+        ids32, t32 = gpu_ctx.trace_closest(g["org"], g["dir"], precision=rt.RT_F32)
+        return ids32, t32
+
+    gpu_ctx.upload(scenes["water"])                 # (something else is resident before each form)
+    gpu_ctx.upload_flat(img)
+    a = check()
+    gpu_ctx.upload(scenes["water"])
+    c = rt.Scene()
+    c.import_flat(img)
+    gpu_ctx.upload(c)
+    b = check()
+    gpu_ctx.upload(scenes["teapot_normal"])
+    ref = check()
+    assert eq(a[0], ref[0]) and eq(a[1], ref[1]) and eq(b[0], ref[0]) and eq(b[1], ref[1])
+
+    # the full pixel path on an imported scene with every kind of record: same frame as from the scene itself
+    def fill(api):
+        m = api.add_texture_bmp(os.path.join(DATA, "tex.bmp"))
+        api.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0, -0.4, 0), True, m)
+        api.add_sphere((0.3, 0.5, 0.5), 0.25, (1, 1, 1, 1.8), 1.5)
+        api.add_sphere((0.3, 0.5, -0.5), 0.2, (1, 0.5, 0.5, 0.6), 1.0)
+        api.add_plane((0.0, 1.0, 0.0), -0.9, (0.5, 0.5, 0.5, 0))
+        api.add_cornell()
+        api.build_bvh()
+        return api
+    s = fill(rt.Scene())
+    p = rt.default_params(width=96, height=64, use_photon_map=0)
+    gpu_ctx.upload(s)
+    rgb0, bgr0, _ = gpu_ctx.render(cam, p)
+    gpu_ctx.upload_flat(s.export_flat())
+    rgb1, bgr1, _ = gpu_ctx.render(cam, p)
+    assert eq(rgb0, rgb1) and eq(bgr0, bgr1) and rgb0.max() > 0
+    with pytest.raises(rt.RtError) as e:
+        gpu_ctx.upload_flat(np.zeros(4096, np.uint8))
+    assert e.value.code == -1
+    rgb2, _, _ = gpu_ctx.render(cam, p)              # a refused image leaves the resident scene as it was
+    assert eq(rgb0, rgb2)

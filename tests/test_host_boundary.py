@@ -109,6 +109,100 @@ def test_forked_bvh_build_equals_serial_tree():
     assert eq(boxes, oboxes)
 
 
+def _textured_scene():
+    """Teapot with texture coordinates and a map, two spheres, a plane and the box: every section of a flat image is non-empty."""
+    s = rt.Scene()
+    m = s.add_texture_bmp(os.path.join(DATA, "tex.bmp"))
+    s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0, 0, 0), True, m)
+    s.add_sphere((0.3, 0.2, 0.5), 0.25, (1, 1, 1, 1.8), 1.5)
+    s.add_sphere((-0.3, -0.2, -0.5), 0.2, (1, 0.5, 0.5, 0.6), 1.0)
+    s.add_plane((0, 1, 0), -0.9, (0.5, 0.5, 0.5, 0))
+    s.add_cornell()
+    s.build_bvh()
+    return s
+
+
+@pytest.mark.parametrize("make", [lambda: build_scene(rt.Scene(), "water.obj"), lambda: build_scene(rt.Scene(), None), _textured_scene, lambda: build_scene(rt.Scene(), None, cornell=False)])
+def test_flat_image_round_trip(make):
+    """export -> import gives the same scene: same tree dump, same objects, and exporting the copy gives the same bytes."""
+    s = make()
+    img = s.export_flat()
+    assert img.ctypes.data % 64 == 0 and img.size % 64 == 0
+    c = rt.Scene()
+    c.load_obj(os.path.join(DATA, "test.obj"))      # (what the scene held before is replaced)
+    c.import_flat(img)
+    assert c.size() == s.size() and c.bvh_depth() == s.bvh_depth()
+    for a, b in zip(s.bvh_dump(), c.bvh_dump()):
+        assert eq(a, b)
+    assert eq(c.export_flat(), img)
+    # an image that arrives at an unaligned address (a slice of a receive buffer) is accepted by the Python wrapper, which copies it
+    raw = np.empty(img.size + 1, np.uint8)
+    raw[1:] = img
+    c2 = rt.Scene()
+    c2.import_flat(raw[1:])
+    assert eq(c2.export_flat(), img)
+    # the C entry point itself refuses it
+    with pytest.raises(rt.RtError) as e:
+        rt._chk(_lib.lib.rt_scene_import_flat(c2.h, raw[1:].ctypes.data, img.size), "rt_scene_import_flat")
+    assert e.value.code == -1 and "aligned" in str(e.value)
+
+
+def test_flat_image_emission_on_the_imported_scene():
+    """Photon emission walks the imported tree exactly as the exported one (same serial generator, same photons)."""
+    s = build_scene(rt.Scene(), "water.obj", (0.26, 0.84, 1.0, 1.8), 1.33)
+    c = rt.Scene()
+    c.import_flat(s.export_flat())
+    assert s.emit_photons(300) == c.emit_photons(300) > 0
+    assert eq(s.photons_get(0), c.photons_get(0))
+
+
+def test_flat_image_is_checked_before_it_is_trusted():
+    """Every field a kernel would follow is validated: a damaged image is refused with RT_ERR_INVALID, never uploaded."""
+    from raytracer_amd import aligned_bytes
+    s = _textured_scene()
+    img = s.export_flat()
+    hdr = np.frombuffer(img[:256].tobytes(), dtype=np.uint8)
+    u64 = lambda off: int(np.frombuffer(img[off:off + 8].tobytes(), np.uint64)[0])
+    n_nodes, n_prims = u64(40), u64(48)
+    off_objects, off_nodes, off_prims, off_texdesc = u64(80), u64(96), u64(104), u64(120)
+    assert n_nodes > 50 and n_prims > 900
+
+    def damaged(edit, size=None):
+        b = aligned_bytes(img.size)
+        b[:] = img
+        edit(b)
+        with pytest.raises(rt.RtError) as e:
+            rt.Scene().import_flat(b[:size] if size else b)
+        assert e.value.code == -1, str(e.value)
+        return str(e.value)
+
+    def put32(b, off, v):
+        b[off:off + 4] = np.frombuffer(np.uint32(v).tobytes(), np.uint8)
+
+    assert "magic" in damaged(lambda b: put32(b, 0, 0x12345678))
+    assert "version" in damaged(lambda b: put32(b, 4, 99))
+    assert "record sizes" in damaged(lambda b: put32(b, 20, 128))
+    assert "truncated" in damaged(lambda b: None, size=img.size - 64)
+    assert "shorter" in damaged(lambda b: None, size=64)
+    assert "offsets" in damaged(lambda b: put32(b, 96, off_nodes + 64))
+    # node 3's first child: points back at node 1 (a cycle), beyond the array, or at primitives that are not there
+    c0 = off_nodes + 3 * 128 + 96
+    assert "pre-order" in damaged(lambda b: put32(b, c0, 1))
+    assert "pre-order" in damaged(lambda b: put32(b, c0, n_nodes + 5))
+    assert "leaf" in damaged(lambda b: put32(b, c0, 0x80000000 | (15 << 27) | (n_prims - 3)))
+    assert "leaf" in damaged(lambda b: put32(b, c0, 0x80000000 | 5))                  # a leaf of no primitives
+    assert "primitive record" in damaged(lambda b: put32(b, off_prims + 7 * 80 + 72, s.size() + 1))
+    assert "texture" in damaged(lambda b: put32(b, off_objects + 5 * 256 + 240, 3))   # object 5's map index
+    assert "texel pool" in damaged(lambda b: put32(b, off_texdesc, 100000))
+    # export into a buffer that is too small
+    n = ctypes.c_size_t(128)
+    small = aligned_bytes(128)
+    assert _lib.lib.rt_scene_export_flat(s.h, small.ctypes.data, ctypes.byref(n)) == -1
+    unbuilt = rt.Scene()
+    unbuilt.load_obj(os.path.join(DATA, "test.obj"))
+    assert _lib.lib.rt_scene_export_flat(unbuilt.h, None, ctypes.byref(n)) == -4
+
+
 def test_reference_main_compiles_against_scene_headers():
     """The drop-in claim at source level: the reference's own main.cpp, untouched, compiles against raytracer_amd/scene/
     (same class names, constructor orders and method names), and so does the main.cpp-style example.  The flags are

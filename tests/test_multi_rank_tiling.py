@@ -59,3 +59,35 @@ def test_two_rank_gather_composes_the_frame(tmp_path):
     org, d = orc.primary_rays(w, h, CAM)
     ids, _ = orc.shoot(org, d)
     assert np.array_equal(np.load(out), ids.reshape(h, w))
+
+
+def _scene_worker(rank, world, port, out_dir):
+    """Rank 0 loads the mesh and builds the tree; the others receive the flat image and never see the mesh file."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    import raytracer_amd as rt
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    build = (lambda: build_scene(rt.Scene(), "water.obj")) if rank == 0 else None
+    img = tiling.broadcast_scene(build, rank, dist, torch)
+    s = rt.Scene()
+    s.import_flat(img)
+    rec, boxes = s.bvh_dump()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), rec=rec, boxes=boxes, n=s.size(), img=np.asarray(img))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_scene_built_once_and_broadcast(tmp_path):
+    """One build, N uploads: the flat image broadcast from rank 0 gives every rank the reference's tree."""
+    import torch.multiprocessing as mp
+    from conftest import golden
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_scene_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = golden("bvh_water.npz")
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    for r in (r0, r1):
+        assert np.array_equal(r["rec"], g["rec"]) and np.array_equal(r["boxes"], g["boxes"]) and int(r["n"]) == 5008
+    assert np.array_equal(r0["img"], r1["img"])
