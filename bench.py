@@ -14,7 +14,10 @@ GPU) and its rows are dealt to the ranks in bands of 8.  The scene is replicated
 resident in HBM before the timed region.  The output is one 32-bit word per pixel: the id of the object
 hit (-1: none), bit 30 set when the hit point lies in shadow.
 
-Rank 0 prints ONE JSON line.  metric = Mrays/s over all closest-hit queries (primary + shadow).
+Rank 0 prints ONE JSON line.  metric = Mrays/s over the rays of a frame: one closest-hit query per pixel (the
+reference's BVH::Shoot) + one shadow ray per hit, which is an any-hit occlusion query, NOT a closest-hit walk (it ends
+at the first occluder).  The same frame with camera rays only (`primary_only`) and with closest-hit shadow rays
+(`shadow_closest_hit`, the work the CPU baseline does per shadow ray) is timed beside it under the same protocol.
 For N > 1 the line also carries strong-scaling figures for the full pixel path on BASELINE's two 8-GPU
 configurations (glass teapot, 3840x2160, depth 4; 10 M triangles, 7680x4320, 16 samples per pixel: rows dealt
 over the GPUs, 8-bit frame gathered to rank 0).
@@ -52,6 +55,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-extras", action="store_true", help="skip the wider configurations reported beside the headline")
+    ap.add_argument("--no-two-ctx", action="store_true", help="skip the two-contexts-alternating figure (its launches overlap: a kernel profile of the headline is taken without it)")
     ap.add_argument("--no-c5", action="store_true", help="skip the 10 M-triangle configuration among them (its host-side scene set-up takes most of a minute)")
     args = ap.parse_args()
 
@@ -186,10 +190,37 @@ def main():
     alg_flop = (rank_rays + 2 * st_work.inner_visits) * 21 + st_work.prim_tests * 51
     achieved_tflops = alg_flop / (avg_kernel_ms * 1e-3) / 1e12
 
+    # ---- the same frame under the same protocol with (a) camera rays only and (b) closest-hit shadow rays: the occluder's
+    # id of every hit, a full BVH::Shoot over the segment walked from the surface (two words per pixel)
+    variants = None
+    if world == 1:
+        shadow_ids = torch.empty((part_rows, w), dtype=torch.int32, device=dev)
+
+        def timed_variant(shadow, d_shadow):
+            p = rt.default_params(width=w, height=h, precision=prec, shadow_rays=shadow)
+            st = ctx.trace_primary_dev(cam, p, (0, part_rows), buf.data_ptr(), None, d_shadow, stats=True)
+            for _ in range(max(2, args.warmup // 5)):
+                ctx.trace_primary_dev(cam, p, (0, part_rows), buf.data_ptr(), None, d_shadow, stats=False)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record(ext)
+            for _ in range(args.steps):
+                ctx.trace_primary_dev(cam, p, (0, part_rows), buf.data_ptr(), None, d_shadow, stats=False)
+            e1.record(ext)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.steps
+            rays = st.primary_rays + st.shadow_rays
+            return {"rays_per_step": int(rays), "ms_per_step": round(ms, 4), "Mrays_per_s": round(rays / ms / 1e3, 2)}
+        variants = {"primary_only": timed_variant(0, None), "shadow_closest_hit": timed_variant(1, shadow_ids.data_ptr())}
+        variants["primary_only"]["work"] = "one closest-hit query (BVH::Shoot) per pixel"
+        variants["shadow_closest_hit"]["work"] = ("camera rays + one closest-hit shadow ray per hit, walked from the surface to the light over the full segment "
+                                                  "(the occluder's id is returned): the query the reference's BVH::Shoot answers, and what cpu_baseline runs")
+        del shadow_ids
+
     # ---- informational: the same frames from two contexts (two streams) of this GPU taking turns, so that the last blocks of
     # one launch run beside the first of the next (never `value`: a step is one launch on one stream)
     two_ctx = None
-    if world == 1:
+    if world == 1 and not args.no_two_ctx:
         try:
             ctx2 = rt.Context(dev_index)
             ctx2.upload(scene)
@@ -239,8 +270,22 @@ def main():
         ids = unfold(folded)
         with open(os.path.join(GOLD, GOLD_HASH_FILE[args.mesh])) as f:
             gold = {l.split()[0]: l.split()[1] for l in f}
+        with open(os.path.join(GOLD, "shadow_frames.txt")) as f:
+            gold_sh = {l.split()[0]: l.split()[1:] for l in f}
+        n_shadowed = int(((folded >= 0) & ((folded & SHADOWED_BIT) != 0)).sum())
         parity = {"f64_id_map_hash": id_map_hash(ids), "golden": gold[tag], "golden_from": "the compiled reference's BVH::Shoot on the same frame",
-                  "ok": id_map_hash(ids) == gold[tag], "pixels_in_shadow": int(((folded >= 0) & ((folded & SHADOWED_BIT) != 0)).sum())}
+                  "ok": id_map_hash(ids) == gold[tag], "pixels_in_shadow": n_shadowed,
+                  # the words of the frame as the timed kernel wrote them (id, bit 30 = in shadow) against the reference's own
+                  # BVH::Shoot on the same occlusion segments (tests/golden/shadow_frames.txt, written by oracle/make_golden.py shadow)
+                  "f64_frame_hash": id_map_hash(folded), "golden_frame": gold_sh[tag][0], "golden_pixels_in_shadow": int(gold_sh[tag][1]),
+                  "shadow_ok": id_map_hash(folded) == gold_sh[tag][0] and n_shadowed == int(gold_sh[tag][1]),
+                  "bars_of_the_other_rows": {
+                      "shaded_frames": ">= 99.9 % of the pixels within 1 LSB of the reference's frame (measured 100 %), tests/test_gpu_render.py",
+                      "knn_counts": "photon counts and k-th distances of findKNN equal the reference's except +-1 photon on <= 1 % of the requests: the device measures float "
+                                    "positions against the 0.28 radius, the reference doubles (tests/test_gpu_render.py::test_knn_counts_and_radius)",
+                      "photon_mapped_pixels": "RMSE < 0.1 8-bit levels against the reference with the same photon list (bound 1.0)",
+                      "subsurface_frames": ">= 99 % of the pixels within 1 LSB and RMSE <= 1 level (measured 99.4 %, 0.25): the march draws from a generator the reference "
+                                           "shares between its threads, so the contract of that row is the RMSE, not the 99.9 % of the other shaded frames"}}
         step(make_params(rt.RT_F32), stats=True)
         torch.cuda.synchronize()
         ids32 = unfold(bufs[(step_no[0] - 1) % n_buf].cpu().numpy().ravel())
@@ -248,16 +293,11 @@ def main():
 
     # HBM traffic and VALU-busy share come from rocprofv3 --pmc passes over this same command (profiles/run_pmc.sh);
     # a benchmark run cannot collect them itself, so they are quoted with their source, not measured here
-    traffic = valu_busy = traffic_source = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            prof = json.load(open(tpath))
-            traffic = prof.get(args.precision)
-            valu_busy = prof.get(args.precision + "_valu_busy")
-            traffic_source = prof.get("source")
-        except Exception:
-            traffic = None
+    prof_all = load_profile_figures()
+    head_prof = prof_all.get("c2", {}).get("trace_primary_kernel<%s>" % ("double" if prec == rt.RT_F64 else "float"), {})
+    traffic = head_prof.get("hbm_side_bytes")
+    valu_busy = head_prof.get("valu_busy")
+    traffic_source = head_prof.get("source")
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -265,17 +305,17 @@ def main():
         if parity is not None and "f32_ids_equal_f32_restatement" in cpu:
             parity["f32_ids_equal_f32_restatement"] = cpu.pop("f32_ids_equal_f32_restatement")
     # the gate: a frame that is not the reference's frame is not a measurement of this path
-    parity_ok = parity is None or (parity["ok"] and parity.get("f32_ids_equal_f32_restatement", True))
+    parity_ok = parity is None or (parity["ok"] and parity["shadow_ok"] and parity.get("f32_ids_equal_f32_restatement", True))
 
     extras = None
     if world == 1 and not args.no_extras:
         try:
-            extras = other_configs(rt, ctx, torch, dev, skip_c5=args.no_c5)
+            extras = other_configs(rt, ctx, torch, dev, prof_all, skip_c5=args.no_c5)
         except Exception as e:     # never lose the headline over them
             extras = {"error": repr(e)}
 
     out = {
-        "metric": "Mrays/s (all closest-hit queries: primary + shadow)",
+        "metric": "Mrays/s (camera rays: one closest-hit query per pixel + shadow rays: one any-hit occlusion query per hit, walked from the light to its first occluder)",
         "value": round(value, 2),
         "unit": "Mrays/s",
         "n_gpus": world,
@@ -288,7 +328,10 @@ def main():
         "dtype": args.precision,
         "data": f"synthetic (scene = {args.mesh} mesh + Cornell box of the reference, camera of main.cpp)",
         "config": {
-            "workload": f"{args.mesh} + Cornell box ({scene.size()} triangles, BVH depth {scene.bvh_depth()}), {w}x{h}, primary + 1 shadow ray per hit",
+            "workload": f"{args.mesh} + Cornell box ({scene.size()} triangles, BVH depth {scene.bvh_depth()}), {w}x{h}, camera rays (closest hit, the reference's BVH::Shoot) "
+                        "+ 1 shadow ray per hit as an any-hit occlusion query walked from the light (less work per ray than a closest-hit walk: see shadow_closest_hit)",
+            "comparable_with_earlier_rounds": "no: round 1 counted closest-hit shadow rays on teapot_normal.obj; since round 2 the mesh is teapot1.obj and the shadow ray stops at "
+                                              "its first occluder -- `shadow_closest_hit` below is the like-for-like figure",
             "rays_per_step": int(rays_per_step),
             "parallelism": f"rows in bands of {tiling.BAND} over {world} GPU(s), scene replicated, RCCL gather to rank 0 overlapped with the next step's kernel"
                            if world > 1 else "1 GPU",
@@ -307,6 +350,8 @@ def main():
             "traffic_source": traffic_source,
             "valu_busy": valu_busy,
             "kernel": "trace_primary_kernel<%s>" % ("double" if prec == rt.RT_F64 else "float"),
+            "profile": {k: head_prof[k] for k in ("calls", "avg_us", "min_us", "max_us", "waves_per_simd", "lanes_per_valu", "l2_hit", "l1_hit") if k in head_prof} or None,
+            "profile_files": traffic_source,
             "kernel_ms_avg": round(avg_kernel_ms, 4),
             "kernel_ms_single_launch": round(single_kernel_ms, 4),
             "algorithmic_flop_per_launch": int(alg_flop),
@@ -326,6 +371,8 @@ def main():
             "note": ("hit ids of the f32 instantiation differ from the reference's (f64) on the fraction of pixels given in "
                      "parity.f32_id_mismatch_fraction (silhouettes); they equal the single-precision restatement's exactly"),
         },
+        "primary_only": variants["primary_only"] if variants else None,
+        "shadow_closest_hit": variants["shadow_closest_hit"] if variants else None,
         "two_contexts_alternating": two_ctx,
         "cpu_baseline": cpu,
         "parity": parity,
@@ -359,11 +406,15 @@ def build_instanced_scene(rt, n_side=100):
         for j in range(n_side):
             s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0.0, i * 1.5, j * 1.5))
     s.build_bvh()
+    return s, instanced_camera(rt, n_side)
+
+
+def instanced_camera(rt, n_side=100):
     c = n_side * 1.5 / 2
-    return s, rt.look_at((n_side * 1.5 * 0.6, c, c), (0.0, c, c))
+    return rt.look_at((n_side * 1.5 * 0.6, c, c), (0.0, c, c))
 
 
-def strong_scaling_leg(rt, ctx, torch, dist, dev, world, rank, ext, what, build, w, h0, **params):
+def strong_scaling_leg(rt, ctx, torch, dist, dev, world, rank, ext, what, build, camera, w, h0, **params):
     """Strong scaling of the full pixel path on one of BASELINE's 8-GPU configurations: the frame's rows are dealt to the
     ranks in bands of 8, every rank renders its bands to 8-bit pixels, rank 0 gathers 3 bytes per pixel over RCCL.
     Collective call on every rank; returns the figures on every rank (rank 0 prints them).  (With one rank -- a rehearsal
@@ -371,16 +422,25 @@ def strong_scaling_leg(rt, ctx, torch, dist, dev, world, rank, ext, what, build,
     import time as _time
 
     from raytracer_amd import tiling
+    image_bytes = 0
     q = tiling.BAND * world
     h = (h0 + q - 1) // q * q                            # whole bands for every rank: h0 rows, or a few more where 8 x ranks does not divide that
     rows = h // world
     p = rt.default_params(width=w, height=h, use_photon_map=0, band_rows=tiling.BAND if world > 1 else 0, n_parts=world, part=rank, **params)
     failed, n_rays = None, 0.0
     cam = None
+    t_setup = _time.perf_counter()
     try:
-        s, cam = build(rt)
-        ctx.upload(s)
-        del s
+        # The scene is built once, on rank 0 (the reference builds its tree once before its threads fan out, main.cpp:678,735),
+        # and reaches the other ranks as a flat image over RCCL: no rank but the first parses a mesh or builds a tree.
+        cam = camera(rt)
+        if world > 1:
+            img = tiling.broadcast_scene(lambda: build(rt)[0], rank, dist, torch, device=dev)
+        else:
+            img = build(rt)[0].export_flat()
+        image_bytes = int(img.size)
+        ctx.upload_flat(img)
+        del img
         part = torch.empty((rows, w, 3), dtype=torch.uint8, device=dev)
         recv = [torch.empty_like(part) for _ in range(world)] if (rank == 0 and world > 1) else None
         st = ctx.render_dev(cam, p, (0, rows), None, part.data_ptr(), stats=True)          # warm-up: queues get allocated here
@@ -394,11 +454,13 @@ def strong_scaling_leg(rt, ctx, torch, dist, dev, world, rank, ext, what, build,
             dist.barrier()
             torch.cuda.synchronize()
 
+    setup_s = torch.tensor([_time.perf_counter() - t_setup], dtype=torch.float64, device=dev)
     ok = torch.tensor([0.0 if failed else 1.0], dtype=torch.float64, device=dev)
     rays = torch.tensor([n_rays], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        dist.all_reduce(setup_s, op=dist.ReduceOp.MAX)
     if ok.item() < 1:
         return {"workload": what, "error": failed or "set-up failed on another rank"}
     reps = 5
@@ -417,7 +479,9 @@ def strong_scaling_leg(rt, ctx, torch, dist, dev, world, rank, ext, what, build,
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     ctx.synchronize()
     return {"workload": what, "scaling": "strong", "n_gpus": world, "rays_per_frame": int(rays.item()), "ms_per_frame": round(float(dt.item()) * 1e3, 3),
-            "Mrays_per_s": round(float(rays.item()) / float(dt.item()) / 1e6, 1), "gather_bytes_per_frame": int(3 * w * h)}
+            "Mrays_per_s": round(float(rays.item()) / float(dt.item()) / 1e6, 1), "gather_bytes_per_frame": int(3 * w * h),
+            "scene_setup_s": round(float(setup_s.item()), 2), "scene_image_bytes": image_bytes,
+            "scene_setup": "built on rank 0, broadcast as a flat image, uploaded by every rank (slowest rank, first frame included)"}
 
 
 def strong_scaling(rt, ctx, torch, dist, dev, world, rank, ext, skip_c5=False):
@@ -425,16 +489,37 @@ def strong_scaling(rt, ctx, torch, dist, dev, world, rank, ext, skip_c5=False):
     gather of each included)."""
     out = {"glass_teapot_3840x2160_depth4": strong_scaling_leg(
         rt, ctx, torch, dist, dev, world, rank, ext, "glass teapot_normal.obj + Cornell box, 3840x2160, depth 4, full pixel path, 8-bit frame gathered to rank 0",
-        build_glass_scene, 3840, 2160)}
+        build_glass_scene, lambda rt: rt.look_at(CAM[:3], CAM[3:]), 3840, 2160)}
     if not skip_c5:
         out["instanced_teapots_10M_triangles_7680x4320_16spp"] = strong_scaling_leg(
             rt, ctx, torch, dist, dev, world, rank, ext,
             "10 000 teapot meshes (9.92 M triangles), 7680x4320, aadepth 4 (16 samples per pixel, 4 distinct rays), full pixel path, 8-bit frame gathered to rank 0",
-            build_instanced_scene, 7680, 4320, aadepth=4)
+            build_instanced_scene, lambda rt: instanced_camera(rt), 7680, 4320, aadepth=4)
     return out
 
 
-def other_configs(rt, ctx, torch, dev, skip_c5=False):
+def load_profile_figures():
+    """profiles/traffic.json: per configuration and kernel family, what rocprofv3 measured over tools/pmc_run.py <cfg> (the
+    same launches as the corresponding part of this file): average duration from --kernel-trace --stats, HBM-side bytes
+    (2 x FETCH_SIZE + WRITE_SIZE), VALU busy, waves per SIMD, L2 hit rate, each with the files under profiles/ it comes
+    from.  A benchmark run cannot collect counters itself, so they are quoted with their source."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        return {}
+
+
+def profile_of(prof_all, cfg, families):
+    """The profiled figures of a configuration's kernels, and their sum of HBM-side bytes per launch x launches per frame."""
+    out = {}
+    for f in families:
+        e = prof_all.get(cfg, {}).get(f)
+        if e:
+            out[f] = {k: e[k] for k in ("calls", "avg_us", "min_us", "max_us", "valu_busy", "waves_per_simd", "lanes_per_valu", "l2_hit", "l1_hit", "hbm_side_bytes", "source") if k in e}
+    return out or None
+
+
+def other_configs(rt, ctx, torch, dev, prof_all, skip_c5=False):
     """The wider configurations on the same GPU, reported beside the headline (never as `value`): the full
     pixel path with the bounce queue (glass teapot, 3840x2160, depth 4), with the photon gather (water
     surface, 1 M photons emitted and both kd-trees built on the device, k = 1000, 1920x1080) and on the
@@ -467,6 +552,7 @@ def other_configs(rt, ctx, torch, dev, skip_c5=False):
         entry["roofline"] = {"bound": "valu", "achieved": round(tf, 3), "peak": VALU_PEAK_TFLOPS["f64"], "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS["f64"], 4),
                              "kernels": "render_primary_kernel + trace_queue_kernel + shade_kernel (3 levels)", "kernels_ms": round(st.trace_kernel_ms, 3),
                              "flop_per_ray": round(flop / rays, 1), "inner_visits_per_ray": round(stc.inner_visits / rays, 3), "prim_tests_per_ray": round(stc.prim_tests / rays, 3)}
+        attach_profile(entry["roofline"], prof_all, "c3", ("render_primary_kernel", "trace_queue_kernel", "shade_kernel"), {"render_primary_kernel": 1, "trace_queue_kernel": 3, "shade_kernel": 4})
     out["glass_teapot_3840x2160_depth4"] = entry
 
     s4 = rt.Scene()
@@ -494,12 +580,16 @@ def other_configs(rt, ctx, torch, dev, skip_c5=False):
         "kernels": "gather_tile_kernel + gather_kernel", "kernels_ms": round(gather_ms, 3), "flop_per_query": k * 38, "bytes_per_query": k * 36,
         "hbm_priced": {"GBps": round(gbytes / (gather_ms * 1e-3) / 1e9, 1), "ratio_to_hbm_peak": round(gbytes / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                        "note": "the 45 MB photon map stays in the Infinity Cache"}}
+    # the per-photon term is evaluated in float by both gather kernels: the same arithmetic against the float vector rate
+    out["water_photon_map_1920x1080_k1000"]["roofline"]["frac_of_f32_rate"] = round(tf / VALU_PEAK_TFLOPS["f32"], 4)
+    attach_profile(out["water_photon_map_1920x1080_k1000"]["roofline"], prof_all, "c4", ("gather_tile_kernel", "gather_stream_kernel", "gather_alongside_kernel", "gather_kernel"),
+                   {"gather_tile_kernel": 1, "gather_stream_kernel": 1, "gather_alongside_kernel": 1, "gather_kernel": 1})
     if not skip_c5:
-        out["instanced_teapots_10M_triangles_7680x4320_16spp"] = config5(rt, ctx, torch, dev)
+        out["instanced_teapots_10M_triangles_7680x4320_16spp"] = config5(rt, ctx, torch, dev, prof_all)
     return out
 
 
-def config5(rt, ctx, torch, dev, n_side=100):
+def config5(rt, ctx, torch, dev, prof_all, n_side=100):
     """BASELINE's fifth configuration on one GPU: 10 000 copies of the teapot mesh (9.92 M triangles, baked -- the reference
     has no instancing) on a 100 x 100 grid, the reference's tree built on the host, 7680 x 4320 at `aadepth 4` through the
     full pixel path.  The reference's pattern shoots 16 samples per pixel of which 4 are distinct rays (both offsets use
@@ -532,7 +622,21 @@ def config5(rt, ctx, torch, dev, n_side=100):
                                      "hbm_priced": {"bytes_per_ray": round((stc.inner_visits * 128 + stc.prim_tests * 80) / rays, 1),
                                                     "GBps": round((stc.inner_visits * 128 + stc.prim_tests * 80) / (st.trace_kernel_ms * 1e-3) / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
                                                     "note": "records the rays touch; the scene (0.9 GB of triangles, 0.1 GB of nodes in f64) is read through L1 and L2"}}
+                attach_profile(entry["roofline"], prof_all, "c5", ("render_primary_kernel",), {"render_primary_kernel": 8})
     return entry
+
+
+def attach_profile(roofline, prof_all, cfg, families, launches_per_frame):
+    """Beside a roofline object: which files under profiles/ reproduce its kernels' times, and the HBM-side bytes of a frame
+    (per-launch figure of each kernel family x its launches per frame), from rocprofv3 over tools/pmc_run.py <cfg>."""
+    prof = profile_of(prof_all, cfg, families)
+    roofline["profile"] = prof
+    roofline["traffic"] = None
+    if prof:
+        total = sum(e.get("hbm_side_bytes", 0) * launches_per_frame.get(f, 1) for f, e in prof.items())
+        roofline["traffic"] = int(total) if total else None
+        roofline["traffic_unit"] = "HBM-side bytes per frame (2 x FETCH_SIZE + WRITE_SIZE per launch x launches per frame)"
+        roofline["profile_files"] = sorted({x for e in prof.values() for x in e.get("source", [])})
 
 
 def _shadow_rays(org, d, ids, t):
@@ -583,7 +687,12 @@ def cpu_baseline(args, w, h, ids32=None):
     from concurrent.futures import ThreadPoolExecutor
 
     from oracle.bindings import Oracle, Reference, have_reference
-    threads = min(16, os.cpu_count() or 1)
+    # the reference runs 2 x hardware_concurrency() threads (main.cpp:690); "hardware" here is this job's share of the host
+    # (the scheduler's affinity mask, and the thread count the environment sets for the job), not the whole machine
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        avail = min(avail, int(os.environ["OMP_NUM_THREADS"]))
+    threads = 2 * max(1, avail)
     orc = Oracle()
     orc.load_obj(os.path.join(DATA, args.mesh))
     orc.add_cornell()
@@ -600,6 +709,10 @@ def cpu_baseline(args, w, h, ids32=None):
         "sample": f"{port_frames} frame(s) of the same {w}x{h} workload (primary + shadow), f64 CPU restatement, {threads} threads; "
                   "traversal time only",
         "cpu_count": os.cpu_count(),
+        "host_cores_available": avail,
+        "thread_shape": "2 x available cores, as main.cpp:690",
+        "query": "every ray, camera and shadow, is a full closest-hit BVH::Shoot (the reference has no any-hit query); the shadow rays cover the same segments as the "
+                 "device's occlusion queries, walked from the light.  Like for like on the device: shadow_closest_hit",
     }
     if ids32 is not None:     # the device's float frame against the single-precision restatement (checker use of the oracle)
         out["f32_ids_equal_f32_restatement"] = bool(np.array_equal(orc.shoot_f32(org, d, threads=threads)[0], ids32))

@@ -269,8 +269,10 @@ int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t 
  * memory (request queue, hand-over list, counters) is a fixed array inside the library, about 7.7 MB on each GPU it
  * runs on, held until the process ends.  The call makes no hipMalloc / hipFree; it is enqueued on the context's
  * stream and not synchronised.  n <= RT_NOALLOC_MAX_REQUESTS, more is refused with RT_ERR_LIMIT.  Every call on a
- * GPU shares that GPU's array: calls that overlap in time on one GPU (two contexts, two streams) race; calls on
- * one context's stream are ordered and safe. */
+ * GPU shares that GPU's array, whichever context it comes through: two calls overlapping in time on one GPU would
+ * race on it, so the library puts them in order -- a call's kernels start only when those of the call before it on
+ * that GPU have finished (a stream wait on an event, no host wait), and the enqueue itself is under a mutex.  Calls
+ * through different contexts of one GPU are therefore safe, and never run side by side. */
 #define RT_NOALLOC_MAX_REQUESTS 65536
 int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int64_t n, const double* d_pos, const double* d_normal,
                                 const double* d_color, double* d_rgb);

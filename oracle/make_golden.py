@@ -462,6 +462,45 @@ def meshes_without_normals():
             f.write(f"{k} {v['hash']} {v['hits']} {v['mesh_hits']} {v['t_sha256']}\n")
 
 
+def occlusion_queries():
+    """G12: the occlusion queries of the benchmark frame (one per camera-ray hit: the segment between the light of
+    main.cpp:654 and the hit point, walked from the light, range |light - P| - 1e-4) answered by the reference's own
+    BVH::Shoot; a pixel is in shadow iff that call returns an object.  The golden is the hash of the frame's words
+    (object id, bit 30 set where the pixel is in shadow) and the number of shadowed pixels."""
+    light = np.array([0.1, 0.2, 0.0])
+    w, h = 1920, 1080
+    rows = []
+    for mesh in ["teapot1.obj", "test.obj", "teapot_normal.obj", "water.obj"]:
+        tag = mesh.split(".")[0]
+        ref = Reference(); orc = Oracle()
+        if mesh in ("teapot1.obj", "test.obj"):
+            assert ref.load_obj_no_normals(os.path.join(DATA, mesh)) == 1
+        else:
+            assert ref.load_obj(os.path.join(DATA, mesh)) == 1
+        assert orc.load_obj(os.path.join(DATA, mesh)) == 1
+        for api in (ref, orc):
+            api.add_cornell(); api.build_bvh()
+        org, d = ref.primary_rays(w, h, CAM)
+        ids, t = ref.shoot(org, d)
+        hit = ids >= 0
+        P = org[hit] + d[hit] * t[hit][:, None]
+        Lv = light - P
+        ln = np.sqrt(Lv[:, 0] * Lv[:, 0] + Lv[:, 1] * Lv[:, 1] + Lv[:, 2] * Lv[:, 2])
+        L = Lv / ln[:, None]
+        from_light = np.broadcast_to(light, L.shape).copy()
+        sid, st = ref.shoot(from_light, -L, ln - 1e-4)
+        oid, ot = orc.shoot_mt(from_light, -L, ln - 1e-4)
+        check(f"occlusion queries from the light {tag} ({int(hit.sum())} segments)", np.c_[sid, st], np.c_[oid, ot])
+        folded = ids.astype(np.int64).copy()
+        sh = np.zeros(w * h, bool)
+        sh[hit] = sid >= 0
+        folded[sh] |= 1 << 30
+        rows.append(f"{tag} {id_map_hash(folded)} {int(sh.sum())}")
+        print("    ", rows[-1])
+    with open(os.path.join(GOLD, "shadow_frames.txt"), "w") as f:
+        f.write("\n".join(rows) + "\n")
+
+
 def finish():
     print()
     if failures:
@@ -471,13 +510,15 @@ def finish():
 
 
 if __name__ == "__main__":
-    # `python oracle/make_golden.py` writes everything; naming sections (base, intended, no_normals) writes only those
-    want = sys.argv[1:] or ["base", "intended", "no_normals"]
+    # `python oracle/make_golden.py` writes everything; naming sections (base, intended, no_normals, shadow) writes only those
+    want = sys.argv[1:] or ["base", "intended", "no_normals", "shadow"]
     os.makedirs(DATA, exist_ok=True)
     if "base" in want:
         main()
     if "intended" in want:
         intended_mode()
+    if "shadow" in want:
+        occlusion_queries()
     if "no_normals" in want:
         meshes_without_normals()
     finish()

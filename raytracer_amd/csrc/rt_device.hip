@@ -113,6 +113,12 @@ static __device__ __align__(256) unsigned char scratch[NA_COUNTERS + NA_QUEUE + 
 // gave for it on the device in question (every GPU holds its own copy of the array at its own address).
 constexpr int NA_MAX_DEVICES = 64;
 static unsigned char* g_scratch_at[NA_MAX_DEVICES];
+// Every call on a GPU uses that GPU's one array, whichever context it comes through.  The calls are therefore put in
+// order: each records g_scratch_done[device] behind its kernels and the next one's stream waits for it (events and
+// stream waits allocate nothing); g_scratch_mu covers the enqueue, so two host threads cannot interleave theirs.
+static hipEvent_t g_scratch_done[NA_MAX_DEVICES];
+static bool g_scratch_used[NA_MAX_DEVICES];
+static std::mutex g_scratch_mu;
 
 struct rt_scene {
     rth::Scene s;
@@ -271,11 +277,12 @@ int launch_batch_t(rt_context* ctx, int64_t n, const double* d_org, const double
     HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
     const int blocks = (int)std::max<int64_t>(1, (n + g.threads - 1) / g.threads);   // one chunk of 64 rays per wave
 #define RT_LAUNCH_BATCH(MODE)                                                                                                                       \
+    if ((rc = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtk::trace_batch_kernel<R, TRI_ONLY, MODE>), g.lds))) return rc;                      \
     hipLaunchKernelGGL((rtk::trace_batch_kernel<R, TRI_ONLY, MODE>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), (long long)n, d_org, \
                        d_dir, d_dist, d_ids, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes)
-    if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_BATCH(rtk::TRAV_NODES);
-    else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_BATCH(rtk::TRAV_RETEST);
-    else RT_LAUNCH_BATCH(rtk::TRAV_PLAIN);
+    if (g.mode == rtk::TRAV_NODES) { RT_LAUNCH_BATCH(rtk::TRAV_NODES); }
+    else if (g.mode == rtk::TRAV_RETEST) { RT_LAUNCH_BATCH(rtk::TRAV_RETEST); }
+    else { RT_LAUNCH_BATCH(rtk::TRAV_PLAIN); }
 #undef RT_LAUNCH_BATCH
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -299,11 +306,12 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
     int wpb = g.threads / 64;
     int blocks = (int)rtk::tile_grid_blocks((a.width + 7) / 8, (a.row_end - a.row_begin + 7) / 8, wpb, g.mode == rtk::TRAV_NODES);
 #define RT_LAUNCH_PRIMARY(MODE)                                                                                                              \
+    if ((rc = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), g.lds))) return rc;     \
     hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, \
                        d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes)
-    if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_PRIMARY(rtk::TRAV_NODES);
-    else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_PRIMARY(rtk::TRAV_RETEST);
-    else RT_LAUNCH_PRIMARY(rtk::TRAV_PLAIN);
+    if (g.mode == rtk::TRAV_NODES) { RT_LAUNCH_PRIMARY(rtk::TRAV_NODES); }
+    else if (g.mode == rtk::TRAV_RETEST) { RT_LAUNCH_PRIMARY(rtk::TRAV_RETEST); }
+    else { RT_LAUNCH_PRIMARY(rtk::TRAV_PLAIN); }
 #undef RT_LAUNCH_PRIMARY
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -364,6 +372,7 @@ int rt_context_create(int device, rt_context** out)
         return fail(RT_ERR_NO_DEVICE, "cannot create a stream on device %d", device);
     }
     // where this device keeps its copy of the fixed working array (once per device, with that device current)
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu);
     if (device < NA_MAX_DEVICES && !g_scratch_at[device]) {
         void* at = nullptr;
         hipError_t se = hipGetSymbolAddress(&at, HIP_SYMBOL(scratch));
@@ -372,11 +381,13 @@ int rt_context_create(int device, rt_context** out)
             delete ctx;
             return fail(RT_ERR_HIP, "hipGetSymbolAddress(scratch) on device %d failed: %s", device, hipGetErrorString(se));
         }
-        // (the hand-over list is all "empty" between calls: set once here, kept so by the kernels that read it)
-        if (hipMemset((unsigned char*)at + NA_COUNTERS + NA_QUEUE, 0xFF, NA_REDO) != hipSuccess) {
+        // (the hand-over list is all "empty" between calls: set once here, kept so by the kernels that read it; the
+        // memset is waited for, since the contexts' streams do not wait for the null stream)
+        if (hipMemset((unsigned char*)at + NA_COUNTERS + NA_QUEUE, 0xFF, NA_REDO) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipEventCreateWithFlags(&g_scratch_done[device], hipEventDisableTiming) != hipSuccess) {
             (void)hipStreamDestroy(ctx->stream);
             delete ctx;
-            return fail(RT_ERR_HIP, "hipMemset(scratch) on device %d failed", device);
+            return fail(RT_ERR_HIP, "setting up the working array on device %d failed", device);
         }
         g_scratch_at[device] = (unsigned char*)at;
     }
@@ -677,17 +688,18 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
         rte::PhotonState* lists[2] = {(rte::PhotonState*)ctx->rays.p, (rte::PhotonState*)ctx->gq.p};
         for (int b = 0; b <= bounce; b++) {
 #define RT_LAUNCH_EMIT(TRI, MODE)                                                                                                                       \
+    if ((rc = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rte::emit_kernel<double, TRI, MODE>), g.lds))) return rc;                               \
     hipLaunchKernelGGL((rte::emit_kernel<double, TRI, MODE>), dim3((unsigned)((a.n_emit + g.threads - 1) / g.threads)), dim3(g.threads), g.lds, ctx->stream, \
                        ctx->v64, sd, a, b, (const rte::PhotonState*)lists[b & 1], lists[(b + 1) & 1], (rte::PhotonOut*)ctx->hits_a.p, cap_s,               \
                        (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap, ctx->n_nodes, order)
             if (tri_only) {
-                if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_EMIT(true, rtk::TRAV_NODES);
-                else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_EMIT(true, rtk::TRAV_RETEST);
-                else RT_LAUNCH_EMIT(true, rtk::TRAV_PLAIN);
+                if (g.mode == rtk::TRAV_NODES) { RT_LAUNCH_EMIT(true, rtk::TRAV_NODES); }
+                else if (g.mode == rtk::TRAV_RETEST) { RT_LAUNCH_EMIT(true, rtk::TRAV_RETEST); }
+                else { RT_LAUNCH_EMIT(true, rtk::TRAV_PLAIN); }
             } else {
-                if (g.mode == rtk::TRAV_NODES) RT_LAUNCH_EMIT(false, rtk::TRAV_NODES);
-                else if (g.mode == rtk::TRAV_RETEST) RT_LAUNCH_EMIT(false, rtk::TRAV_RETEST);
-                else RT_LAUNCH_EMIT(false, rtk::TRAV_PLAIN);
+                if (g.mode == rtk::TRAV_NODES) { RT_LAUNCH_EMIT(false, rtk::TRAV_NODES); }
+                else if (g.mode == rtk::TRAV_RETEST) { RT_LAUNCH_EMIT(false, rtk::TRAV_RETEST); }
+                else { RT_LAUNCH_EMIT(false, rtk::TRAV_PLAIN); }
             }
 #undef RT_LAUNCH_EMIT
             HIP_TRY(hipGetLastError());
@@ -1543,6 +1555,9 @@ int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int6
     if (ctx->device >= NA_MAX_DEVICES || !g_scratch_at[ctx->device]) return fail(RT_ERR_STATE, "no working array on device %d", ctx->device);
     if ((rc = use_device(ctx))) return rc;
     unsigned char* const base = g_scratch_at[ctx->device];          // the device address, never the symbol's name
+    // one call at a time on this GPU's array: behind the kernels of the call before, whichever context made it
+    std::lock_guard<std::mutex> scratch_lock(g_scratch_mu);
+    if (g_scratch_used[ctx->device]) HIP_TRY(hipStreamWaitEvent(ctx->stream, g_scratch_done[ctx->device], 0));
     rtr::RenderCounters* ctr = (rtr::RenderCounters*)base;
     rtg::GatherRec* recs = (rtg::GatherRec*)(base + NA_COUNTERS);
     uint32_t* redo = (uint32_t*)(base + NA_COUNTERS + NA_QUEUE);
@@ -1560,8 +1575,11 @@ int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int6
     gp.norm = (double)(p->photon_num / 16) * 3.1415926;
     gp.photon_num = (double)p->photon_num;
     gp.seed = 12345u;
-    return launch_gather(ctx, recs, &ctr->gather, (unsigned long long)slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, ctr->tile_progress, gp, d_rgb, redo,
-                         NA_REDO / sizeof(uint32_t), false);
+    rc = launch_gather(ctx, recs, &ctr->gather, (unsigned long long)slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, ctr->tile_progress, gp, d_rgb, redo,
+                       NA_REDO / sizeof(uint32_t), false);
+    // (recorded even when a launch failed part-way: whatever did get enqueued uses the array)
+    if (hipEventRecord(g_scratch_done[ctx->device], ctx->stream) == hipSuccess) g_scratch_used[ctx->device] = true;
+    return rc;
     });
 }
 }  // extern "C"
@@ -1647,15 +1665,20 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int wpb = g.threads / 64;
     const dim3 grid((unsigned)rtk::tile_grid_blocks((a.col_end - a.col_begin + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth));
-    if (COUNT)
+    int rc_lds;
+    if (COUNT) {
+        if ((rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::render_primary_kernel<R, TRI_ONLY, MODE, false, COUNT>), g.lds))) return rc_lds;
         hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE, false, COUNT>), grid, dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
                            (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
-    else if (a.dof_samples > 1)
+    } else if (a.dof_samples > 1) {
+        if ((rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::render_primary_kernel<R, TRI_ONLY, MODE, true>), g.lds))) return rc_lds;
         hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE, true>), grid, dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
                            (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
-    else
+    } else {
+        if ((rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::render_primary_kernel<R, TRI_ONLY, MODE, false>), g.lds))) return rc_lds;
         hipLaunchKernelGGL((rtr::render_primary_kernel<R, TRI_ONLY, MODE, false>), grid, dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
                            (rtr::HitRec*)ctx->hits_a.p, shard_cap, ctr, cap, ctx->n_nodes, d_acc);
+    }
     HIP_TRY(hipGetLastError());
     // persistent grids for the queue consumers (their work counts live in device memory)
     // (the queue tracer is held to 128 registers: four waves per SIMD, sixteen per CU)
@@ -1709,9 +1732,11 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
                 if (int rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::trace_queue_kernel<R, TRI_ONLY, rtk::TRAV_NODES, COUNT>), nodes_lds)) return rc_lds;
                 hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, rtk::TRAV_NODES, COUNT>), dim3(ctx->num_cus), dim3(nodes_waves * 64), nodes_lds, ctx->stream,
                                    view<R>(ctx), a, level, (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes, ctx->n_prims);
-            } else
+            } else {
+                if ((rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::trace_queue_kernel<R, TRI_ONLY, MODE, COUNT>), g.lds))) return rc_lds;
                 hipLaunchKernelGGL((rtr::trace_queue_kernel<R, TRI_ONLY, MODE, COUNT>), dim3(trace_blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, level,
                                    (const rtr::RayRec*)ctx->rays.p, qout, shard_cap, ctr, cap, ctx->n_nodes, ctx->n_prims);
+            }
             HIP_TRY(hipGetLastError());
         }
         std::swap(qin, qout);
@@ -1785,6 +1810,14 @@ int render_block(rt_context* ctx, const rtr::RenderArgs& a, const rt_render_para
     if (rc) return rc;
     if (ev_end) HIP_TRY(hipEventRecord(ev_end, ctx->stream));
     if (p->use_photon_map && (ctx->pm[0].n > 0 || ctx->pm[1].n > 0)) {
+        if (caps.retry && ctr_copy) {
+            // Queues that are a budget: a part whose rays outgrew them is rendered again in pieces, so its gather would be
+            // work thrown away, over a request queue whose fill counters exceed its capacity.  The caller waits for every
+            // part anyway; wait here, and leave the gather out when the part overflowed.
+            HIP_TRY(hipMemcpyAsync(ctr_copy, ctr, sizeof(*ctr_copy), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (ctr_copy->overflow_queue || ctr_copy->overflow_stack) return RT_OK;
+        }
         rtg::GatherParams gp;
         gp.front_cap = gather_front_cap();
         gp.k = p->photon_use;

@@ -71,12 +71,19 @@ def broadcast_scene(build, rank, dist, torch, device=None):
 
     from . import aligned_bytes
     img = None
+    failure = None
     n = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == 0:
-        img = build().export_flat()
-        n[0] = img.size
+        try:
+            img = build().export_flat()
+            n[0] = img.size
+        except Exception as e:      # (the other ranks are waiting in the collective below: tell them instead of leaving them there)
+            failure = e
+            n[0] = -1
     dist.broadcast(n, src=0)
     size = int(n.item())
+    if size < 0:
+        raise RuntimeError("rank 0 could not build the scene") from failure
     if rank == 0:
         t = torch.from_numpy(img)
     else:

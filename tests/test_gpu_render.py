@@ -454,6 +454,8 @@ def test_render_deeper_than_the_default(gpu_ctx, monkeypatch, depth):
     small, _, st_small = gpu_ctx.render(cam, p)
     monkeypatch.delenv("RT_SHARD_CAP")
     assert st_small.secondary_rays == st.secondary_rays and np.abs(small - rgb).max() < 1e-9
+    # (a part that overflowed is split before its photon gather is launched: only the parts that fit gather, once each)
+    assert st_small.gather_queries == st.gather_queries
 
 
 @pytest.mark.parametrize("head_quirk", [0, 1])

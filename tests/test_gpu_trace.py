@@ -488,3 +488,59 @@ def test_scene_uploaded_from_a_flat_image(gpu_ctx, scenes):
     assert e.value.code == -1
     rgb2, _, _ = gpu_ctx.render(cam, p)              # a refused image leaves the resident scene as it was
     assert eq(rgb0, rgb2)
+
+
+@pytest.mark.parametrize("tag", ["teapot1", "test", "teapot_normal", "water"])
+def test_occlusion_frame_equals_the_reference(gpu_ctx, tag):
+    """The benchmark's frame -- one word per pixel, bit 30 set where the any-hit query between light and hit point found
+    an occluder -- against the reference's own BVH::Shoot on the same segments (tests/golden/shadow_frames.txt): any
+    occluder found is an occluder, so the early exit must not change a single bit of the 1920x1080 frame."""
+    import ctypes
+    with open(os.path.join(os.path.dirname(DATA), "shadow_frames.txt")) as f:
+        gold = {l.split()[0]: l.split()[1:] for l in f}
+    gpu_ctx.upload(build_scene(rt.Scene(), tag + ".obj"))
+    w, h = 1920, 1080
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")
+    d_ids = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(d_ids), ctypes.c_size_t(w * h * 4)) == 0
+    gpu_ctx.trace_primary_dev(rt.look_at(CAM[:3], CAM[3:]), rt.default_params(width=w, height=h, shadow_rays=2), (0, h), d_ids, None, None)
+    folded = np.zeros(w * h, np.int32)
+    assert hip.hipMemcpy(folded.ctypes.data_as(ctypes.c_void_p), d_ids, ctypes.c_size_t(w * h * 4), 2) == 0
+    assert hip.hipFree(d_ids) == 0
+    n_sh = int(((folded >= 0) & ((folded & (1 << 30)) != 0)).sum())
+    assert [id_map_hash(folded), str(n_sh)] == gold[tag]
+
+
+def test_blocks_with_more_than_64k_of_lds(gpu_ctx, scenes, monkeypatch):
+    """Blocks of 8 waves over a staged node image take more than 64 KiB of dynamic LDS (8 stacks + the node array), which
+    a launch is only given once the kernel has been allowed it: every entry point that sizes its blocks this way -- batch
+    rays, camera rays, the pixel path and photon emission -- must still launch and return the golden results."""
+    monkeypatch.setenv("RT_BLOCK_WAVES", "12")
+    monkeypatch.setenv("RT_TRAV_MODE", "plain")
+    monkeypatch.setenv("RT_TRACE_GEOM", "1")
+    gpu_ctx.upload(scenes["teapot_normal"])
+    g = golden("rays_teapot_normal.npz")
+    ids, t = gpu_ctx.trace_closest(g["org"], g["dir"])
+    assert eq(ids, g["ids"]) and eq(t, g["t"])
+    ids32, _ = gpu_ctx.trace_closest(g["org"], g["dir"], precision=rt.RT_F32)
+    h = golden("hits_teapot_normal_96x54.npz")
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    ids, t, _, _ = gpu_ctx.trace_primary(cam, rt.default_params(width=96, height=54))
+    assert eq(ids.ravel(), h["ids"].ravel()) and eq(np.where(ids >= 0, t, 1e9).ravel(), h["t"].ravel())
+    s = build_scene(rt.Scene(), "teapot_normal.obj", (1.0, 1.0, 1.0, 1.8), 1.5, (0, -0.7, 0))
+    gpu_ctx.upload(s)
+    p = rt.default_params(width=96, height=64, use_photon_map=0)
+    big, _, st_big = gpu_ctx.render(cam, p)
+    st_emit = s.emit_photons_gpu(gpu_ctx, 20000, seed=3)
+    n_big = s.photon_count(0)
+    s.photons_clear()
+    for k in ("RT_BLOCK_WAVES", "RT_TRAV_MODE", "RT_TRACE_GEOM"):
+        monkeypatch.delenv(k)
+    gpu_ctx.upload(scenes["teapot_normal"])
+    ref32, _ = gpu_ctx.trace_closest(g["org"], g["dir"], precision=rt.RT_F32)
+    assert eq(ids32, ref32)
+    gpu_ctx.upload(s)
+    plain, _, st_plain = gpu_ctx.render(cam, p)
+    assert eq(big, plain) and st_big.secondary_rays == st_plain.secondary_rays > 0
+    s.emit_photons_gpu(gpu_ctx, 20000, seed=3)
+    assert s.photon_count(0) == n_big > 20000 and st_emit.secondary_rays > 20000

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import CAM, DATA, build_scene, golden, golden_hashes
+from conftest import CAM, DATA, GOLD, build_scene, golden, golden_hashes
 from oracle.bindings import Oracle, id_map_hash
 
 
@@ -400,3 +400,30 @@ def test_mesh_without_normals_golden(tag):
     h = golden_hashes("idmap_hashes_no_normals.txt")[tag]
     assert id_map_hash(ids) == h["hash"] and int((ids >= 0).sum()) == h["hits"]
     assert hashlib.sha256(t.tobytes()).hexdigest() == h["t_sha256"]
+
+
+def test_occlusion_frame_golden():
+    """tests/golden/shadow_frames.txt (the reference's own BVH::Shoot on the benchmark frame's occlusion segments, walked
+    from the light): the restatement answers the same queries the same way -- frame words (object id, bit 30 = in shadow)
+    hashed, and the number of shadowed pixels.  The benchmark gates its headline on these values."""
+    from oracle.bindings import id_map_hash
+    with open(os.path.join(GOLD, "shadow_frames.txt")) as f:
+        gold = {l.split()[0]: l.split()[1:] for l in f}
+    assert set(gold) == {"teapot1", "test", "teapot_normal", "water"}
+    light = np.array([0.1, 0.2, 0.0])
+    w, h = 1920, 1080
+    for tag in ("teapot1",):
+        orc = build_scene(Oracle(), tag + ".obj")
+        org, d = orc.primary_rays(w, h, CAM)
+        ids, t = orc.shoot_mt(org, d)
+        hit = ids >= 0
+        P = org[hit] + d[hit] * t[hit][:, None]
+        Lv = light - P
+        ln = np.sqrt(Lv[:, 0] * Lv[:, 0] + Lv[:, 1] * Lv[:, 1] + Lv[:, 2] * Lv[:, 2])
+        L = Lv / ln[:, None]
+        sid, _ = orc.shoot_mt(np.broadcast_to(light, L.shape).copy(), -L, ln - 1e-4)
+        folded = ids.astype(np.int64).copy()
+        sh = np.zeros(w * h, bool)
+        sh[hit] = sid >= 0
+        folded[sh] |= 1 << 30
+        assert [id_map_hash(folded), str(int(sh.sum()))] == gold[tag]

@@ -43,15 +43,25 @@ def test_no_alloc_gather_matches_grouped_entry_point():
         assert hip.hipMemcpy(p, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes), 1) == 0
         return p
 
+    def free_bytes():
+        free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
     for k, n in ((1000, 12000), (1000, 3777), (50, 64), (50, 1)):          # second and later calls are smaller
         p = rt.default_params(photon_use=k)
         pos, nrm, col = pos_all[:n], nrm_all[:n], col_all[:n]
         want = ctx.knn_estimate_grouped(p, pos, nrm, col)
         d_pos, d_nrm, d_col = dev(pos), dev(nrm), dev(col)
         d_rgb = dev(np.full((n, 3), 7.0))                                   # stale values in the output must not survive
+        ctx.synchronize()
+        before = free_bytes()
         rc = _lib.lib.rt_knn_estimate_dev_noalloc(ctx.h, ctypes.byref(p), n, d_pos, d_nrm, d_col, d_rgb)
         assert rc == 0, _lib.lib.rt_last_error()
+        during = free_bytes()                                               # (the kernels may still be running)
         ctx.synchronize()
+        # the device's free memory is what it was: the call allocated nothing and freed nothing
+        assert before == during == free_bytes(), (before, during, free_bytes())
         got = np.zeros((n, 3))
         assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), d_rgb, ctypes.c_size_t(got.nbytes), 2) == 0
         for q in (d_pos, d_nrm, d_col, d_rgb):
@@ -60,6 +70,29 @@ def test_no_alloc_gather_matches_grouped_entry_point():
         # same kernels over the same groups: the sums may run in another order only where a request went to the
         # one-request-per-wave kernel, whose candidate order depends on the bound its predecessor handed over
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, want.max()), (k, n, np.abs(got - want).max())
+    # Two contexts of the one GPU call it back to back without waiting in between: both use the GPU's one array, so the
+    # library orders the second behind the first, and each gets the answers it gets when called alone -- whatever the
+    # other's requests left in the queue, the counters and the hand-over list.
+    ctx2 = rt.Context(0)
+    ctx2.photons_upload(g["photons"])
+    ctx2.upload(s)
+    p = rt.default_params(photon_use=1000)
+    na, nb = 9000, 2500
+    want_a = ctx.knn_estimate_grouped(p, pos_all[:na], nrm_all[:na], col_all[:na])
+    want_b = ctx2.knn_estimate_grouped(p, pos_all[-nb:], nrm_all[-nb:], col_all[-nb:])
+    bufs_a = [dev(x) for x in (pos_all[:na], nrm_all[:na], col_all[:na], np.full((na, 3), 7.0))]
+    bufs_b = [dev(x) for x in (pos_all[-nb:], nrm_all[-nb:], col_all[-nb:], np.full((nb, 3), 7.0))]
+    for rep in range(2):
+        assert _lib.lib.rt_knn_estimate_dev_noalloc(ctx.h, ctypes.byref(p), na, *bufs_a) == 0, _lib.lib.rt_last_error()
+        assert _lib.lib.rt_knn_estimate_dev_noalloc(ctx2.h, ctypes.byref(p), nb, *bufs_b) == 0, _lib.lib.rt_last_error()
+    ctx.synchronize(); ctx2.synchronize()
+    for bufs, want, n in ((bufs_a, want_a, na), (bufs_b, want_b, nb)):
+        got = np.zeros((n, 3))
+        assert hip.hipMemcpy(got.ctypes.data_as(ctypes.c_void_p), bufs[3], ctypes.c_size_t(got.nbytes), 2) == 0
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, want.max()), np.abs(got - want).max()
+        for q in bufs:
+            assert hip.hipFree(q) == 0
+    del ctx2
     # beyond the fixed working memory: refused, nothing launched
     p = rt.default_params()
     d_any = dev(np.zeros(8))
