@@ -477,7 +477,9 @@ def test_scene_uploaded_from_a_flat_image(gpu_ctx, scenes):
         api.build_bvh()
         return api
     s = fill(rt.Scene())
-    p = rt.default_params(width=96, height=64, use_photon_map=0)
+    s.emit_photons(4000, seed=7)
+    gpu_ctx.photons_upload(s.photons_get(0))         # (the reference has no direct light: a frame without a photon map is black)
+    p = rt.default_params(width=96, height=64, photon_num=4000, photon_use=50)
     gpu_ctx.upload(s)
     rgb0, bgr0, _ = gpu_ctx.render(cam, p)
     gpu_ctx.upload_flat(s.export_flat())
