@@ -484,12 +484,13 @@ def test_scene_uploaded_from_a_flat_image(gpu_ctx, scenes):
     rgb0, bgr0, _ = gpu_ctx.render(cam, p)
     gpu_ctx.upload_flat(s.export_flat())
     rgb1, bgr1, _ = gpu_ctx.render(cam, p)
-    assert eq(rgb0, rgb1) and eq(bgr0, bgr1) and rgb0.max() > 0
+    # (two renders of one scene agree to the order of the per-pixel atomic additions, not bit for bit)
+    assert np.abs(rgb0 - rgb1).max() <= 1e-12 and eq(bgr0, bgr1) and rgb0.max() > 0
     with pytest.raises(rt.RtError) as e:
         gpu_ctx.upload_flat(np.zeros(4096, np.uint8))
     assert e.value.code == -1
     rgb2, _, _ = gpu_ctx.render(cam, p)              # a refused image leaves the resident scene as it was
-    assert eq(rgb0, rgb2)
+    assert np.abs(rgb0 - rgb2).max() <= 1e-12
 
 
 @pytest.mark.parametrize("tag", ["teapot1", "test", "teapot_normal", "water"])
