@@ -1,0 +1,713 @@
+// K4, the form the pixel path uses: the photon gather for a GROUP of up to 64 neighbouring requests per wave, one
+// request per lane (KDTree::findKNN, Kdtree.cpp:73-158, + the estimate of main.cpp:260-295), over a PACKED list of
+// the group's photons.
+//
+// The requests one shading wave queues are hit points a few pixel footprints apart; their k-nearest balls overlap
+// almost entirely.  A wave takes such a window and
+//   1. picks the middle request as the round's centre and finds its k-th nearest distance r_c with all 64 lanes
+//      working on that one request: the tree is walked for a box of a guessed radius (the wave's last r_c, grown
+//      or shrunk until it holds k photons and fits the lists), the photons of the listed leaves that lie within
+//      reach of the centre are written, in tree order, to the wave's packed list in global memory, and four
+//      radix passes over that list (lane j measuring photon j) give the exact bit pattern of the k-th smallest
+//      squared distance;
+//   2. derives every other request's search range from r_c (triangle inequality, narrowed to r_c (1 -+ rho) and
+//      checked by counting), and filters the packed list in place down to the photons inside the box around the
+//      round's balls and within reach of the centre -- a list that depends on the window alone, not on the guess,
+//      so the sums below run in the same order whichever wave takes the window;
+//   3. streams the packed list three times, every lane measuring its own distance to the same photon (a step's
+//      64 photons are staged in LDS and read back as broadcasts, four at a time):
+//        a. a histogram per lane over the shell between its two radii locates the bin of its k-th distance,
+//        b. the distances of that bin (a few dozen) are kept and ranked: the exact k-th distance and its ties,
+//        c. the radiance estimate is accumulated over the set, which is never stored.
+// A group lists the photons of every leaf its box touches (about 5 500 at k = 1000 on a surface map of 47 000
+// photons per unit area) but only a third of them lie inside some request's ball; packing makes the three passes
+// stream that third, in full steps of 64, from one contiguous list.  Nothing here needs the per-request search,
+// whose candidate buffer and registers would cap the kernel at two waves per SIMD.
+//
+// Same exact k-nearest set as the per-request form (rt_gather.hip.h): the search radius is exclusive in both,
+// photons at exactly the k-th distance either all belong or the request is handed on.  Requests a group cannot
+// take (other materials' terms, rounds of a few requests, a range that fails its check, a crowded bin, lists that
+// overflow) go to the hand-over list, which the per-request kernel works off.
+#pragma once
+#include "rt_gather_tile.hip.h"
+
+namespace rtg {
+
+constexpr int S_PACK_CAP = 4096;      // photons the packed list of a wave holds (16 bytes each)
+constexpr int S_ATTEMPTS = 7;         // guesses at the centre's radius per round before the round is handed on
+
+// Per-wave LDS of the kernel: 12.5 KB, so that twelve waves share a CU.  The per-lane tables of the passes lie over
+// what the walk and the sort of its lists need, which is dead once the packed list exists.
+struct StreamLds {
+    union {
+        uint32_t table[(T_BINS / 2) * WAVE];      // histograms: [bin][32 words], two 16-bit counts each; critical bin: [T_CRIT][64]
+        struct {
+            uint32_t leaf[T_LEAVES], piv[T_PIVOTS];           // as the walk lists them
+            int f_lo[FRONT], f_hi[FRONT];                     // the walk's frontier
+            uint32_t leaf_sorted[T_LEAVES], piv_sorted[T_PIVOTS];
+        } w;
+    };
+    float stage[9 * WAVE];                        // a step's photons: x[64] y[64] z[64] (+ power, direction in a sum pass); the radix histogram of step 1
+};
+static_assert(T_CRIT * WAVE <= (T_BINS / 2) * WAVE && sizeof(StreamLds) <= 13 * 1024, "twelve waves per CU");
+__shared__ StreamLds g_S;
+
+typedef float4 __attribute__((address_space(1))) gfloat4;
+__device__ __forceinline__ float4 load_global4(const float4* p)
+{
+    const gfloat4* g = (const gfloat4*)p;
+    return *g;
+}
+
+// ---- the walk: leaves and pivots inside the box [gl, gh] -> g_S.w.leaf / piv; n_leaf | n_piv << 16, or -1 when the
+// box touches more of the tree than the lists hold
+__device__ __attribute__((noinline)) int stream_walk(PhotonMapView pm, float glx, float gly, float glz, float ghx, float ghy, float ghz)
+{
+    StreamLds& S = g_S;
+    const int lane = lane_id();
+    int n_leaf = 0, n_piv = 0, nf = 1;
+    if (lane == 0) { S.w.f_lo[0] = 0; S.w.f_hi[0] = (int)pm.n; }
+    __builtin_amdgcn_wave_barrier();
+    while (nf > 0) {
+        const int take = nf < WAVE ? nf : WAVE;
+        const int base = nf - take;
+        nf = base;
+        int rlo = 0, rhi = 0;
+        if (lane < take) { rlo = S.w.f_lo[base + lane]; rhi = S.w.f_hi[base + lane]; }
+        const bool live = lane < take && rhi > rlo;
+        const bool small = live && rhi - rlo <= WAVE;
+        bool is_leaf = small;
+        if (is_leaf) {
+            const float* b = pm.leaf_box + 6 * (size_t)(rlo >> 5);
+            is_leaf = !(b[0] > ghx || b[3] < glx || b[1] > ghy || b[4] < gly || b[2] > ghz || b[5] < glz);
+        }
+        const bool is_inner = live && !small;
+        int mid = 0;
+        bool piv_in = false, go_l = false, go_r = false;
+        if (is_inner) {
+            mid = rlo + (rhi - rlo) / 2;
+            const float4 pv = pm.pos[mid];
+            const int ax = (int)pv.w;
+            piv_in = !(pv.x > ghx || pv.x < glx || pv.y > ghy || pv.y < gly || pv.z > ghz || pv.z < glz);
+            const float split = ax == 0 ? pv.x : (ax == 1 ? pv.y : pv.z);
+            const float lo_ax = ax == 0 ? glx : (ax == 1 ? gly : glz), hi_ax = ax == 0 ? ghx : (ax == 1 ? ghy : ghz);
+            go_l = lo_ax <= split && mid > rlo;           // the left side holds coordinates <= split
+            go_r = hi_ax >= split && rhi > mid + 1;       // the right side holds coordinates >= split
+        }
+        const unsigned long long m_leaf = __ballot(is_leaf), m_piv = __ballot(piv_in), m_l = __ballot(go_l), m_r = __ballot(go_r);
+        const int c_leaf = __builtin_popcountll(m_leaf), c_piv = __builtin_popcountll(m_piv), c_l = __builtin_popcountll(m_l), c_r = __builtin_popcountll(m_r);
+        __builtin_amdgcn_wave_barrier();
+        if (n_leaf + c_leaf > T_LEAVES || n_piv + c_piv > T_PIVOTS || nf + c_l + c_r > FRONT) return -1;
+        if (is_leaf) S.w.leaf[n_leaf + (int)prefix_rank(m_leaf)] = ((uint32_t)rlo << 7) | (uint32_t)(rhi - rlo);
+        if (piv_in) S.w.piv[n_piv + (int)prefix_rank(m_piv)] = (uint32_t)mid;
+        if (go_l) { const int p = nf + (int)prefix_rank(m_l); S.w.f_lo[p] = rlo; S.w.f_hi[p] = mid; }
+        if (go_r) { const int p = nf + c_l + (int)prefix_rank(m_r); S.w.f_lo[p] = mid + 1; S.w.f_hi[p] = rhi; }
+        n_leaf += c_leaf; n_piv += c_piv; nf += c_l + c_r;
+        __builtin_amdgcn_wave_barrier();
+    }
+    return n_leaf | (n_piv << 16);
+}
+
+// dst[rank of src[i] among src[0..n)] = src[i]: the entries are distinct (tree positions), n is a few hundred
+__device__ __forceinline__ void rank_sort(const uint32_t* src, uint32_t* dst, int n)
+{
+    const int lane = lane_id();
+    for (int i0 = 0; i0 < n; i0 += WAVE) {
+        const int i = i0 + lane;
+        const uint32_t e = src[i < n ? i : n - 1];
+        int rank = 0;
+#pragma unroll 4
+        for (int j = 0; j < n; j++) rank += src[j] < e ? 1 : 0;
+        if (i < n) dst[rank] = e;
+    }
+}
+
+// Step s of the sorted lists: lane j's tree position (clamped to a valid one) and the photons in the step.
+__device__ __forceinline__ int list_step(int s, int n_leaf, int n_piv, int lane, int& n)
+{
+    const StreamLds& S = g_S;
+    if (s < n_leaf) {
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.w.leaf_sorted[s]);
+        n = (int)(e & 127u);
+        return (int)(e >> 7) + (lane < n ? lane : n - 1);
+    }
+    const int first = (s - n_leaf) * WAVE;
+    n = n_piv - first < WAVE ? n_piv - first : WAVE;
+    return (int)S.w.piv_sorted[first + (lane < n ? lane : n - 1)];
+}
+
+// ---- packing, first stage: the photons of the listed leaves and pivots within sqrt(reach2) of the centre, in tree
+// order, as (x, y, z, tree position).  Returns their number, or -1 when they exceed the list.
+__device__ __attribute__((noinline)) int pack_listed(const float4* __restrict__ pos, float4* pack, float cx, float cy, float cz, float reach2, int n_leaf, int n_piv)
+{
+    const int lane = lane_id();
+    n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);
+    const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
+    int out = 0, n = 0, n_next = 0;
+    int at = n_steps > 0 ? list_step(0, n_leaf, n_piv, lane, n) : 0, at_next = 0;
+    float4 p = n_steps > 0 ? load_global4(pos + at) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_steps; s++) {
+        // the next step's photons are on their way while this step's are filtered (the fetch is unconditional: one
+        // inside a branch is waited for at the branch's end)
+        at_next = list_step(s + 1 < n_steps ? s + 1 : s, n_leaf, n_piv, lane, n_next);
+        const float4 p_next = load_global4(pos + at_next);
+        const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+        const bool keep = lane < n && dx * dx + dy * dy + dz * dz <= reach2;
+        const unsigned long long m = __ballot(keep);
+        const int c = __builtin_popcountll(m);
+        if (out + c > S_PACK_CAP) return -1;
+        if (keep) pack[out + (int)prefix_rank(m)] = float4{p.x, p.y, p.z, __uint_as_float((uint32_t)at)};
+        out += c;
+        p = p_next; at = at_next; n = n_next;
+    }
+    return out;
+}
+
+// a step of the packed list: lane j's entry (clamped) and the entries in the step
+__device__ __forceinline__ float4 pack_step(const float4* pack, int s, int n_pack, int lane, int& n)
+{
+    const int first = s * WAVE;
+    n = n_pack - first < WAVE ? n_pack - first : WAVE;
+    return load_global4(pack + first + (lane < n ? lane : n - 1));
+}
+
+// ---- packing, second stage, in place: what lies inside the box [gl, gh] and within sqrt(reach2) of the centre
+struct Box6f { float lx, ly, lz, hx, hy, hz; };
+__device__ __attribute__((noinline)) int pack_refilter(float4* pack, int n_pack, float cx, float cy, float cz, float reach2, Box6f bx)
+{
+    const int lane = lane_id();
+    n_pack = __builtin_amdgcn_readfirstlane(n_pack);
+    const int n_steps = (n_pack + WAVE - 1) / WAVE;
+    int out = 0, n = 0, n_next = 0;
+    float4 p = n_steps > 0 ? pack_step(pack, 0, n_pack, lane, n) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_steps; s++) {
+        const float4 p_next = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);      // (lies wholly behind what this step writes)
+        const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+        const bool inside = !(p.x > bx.hx || p.x < bx.lx || p.y > bx.hy || p.y < bx.ly || p.z > bx.hz || p.z < bx.lz);
+        const bool keep = lane < n && inside && dx * dx + dy * dy + dz * dz <= reach2;
+        const unsigned long long m = __ballot(keep);
+        // the step's entries are all in registers before any of its outputs is written, and outputs never pass the step
+        __builtin_amdgcn_wave_barrier();
+        if (keep) pack[out + (int)prefix_rank(m)] = p;
+        out += __builtin_popcountll(m);
+        p = p_next; n = n_next;
+    }
+    return out;
+}
+
+// ---- the centre's k-th smallest squared distance among the packed photons with d2 < lim, by all lanes together:
+// most-significant-byte-first radix passes over the bit patterns (non-negative floats order like their bits).
+// Returns the bit pattern; *total = photons with d2 < lim (fewer than k: the return value means nothing).
+__device__ __attribute__((noinline)) uint32_t centre_kth(const float4* pack, int n_pack, float cx, float cy, float cz, float lim, int k, int* total)
+{
+    uint32_t* const hist = reinterpret_cast<uint32_t*>(g_S.stage);      // 256 words of the staging area, idle here
+    const int lane = lane_id();
+    n_pack = __builtin_amdgcn_readfirstlane(n_pack);
+    const int n_steps = (n_pack + WAVE - 1) / WAVE;
+    uint32_t prefix = 0, pmask = 0;
+    int want = k;
+    for (int pass = 3; pass >= 0; pass--) {
+        for (int b = lane; b < 256; b += WAVE) hist[b] = 0;
+        __builtin_amdgcn_wave_barrier();
+        int n = 0, n_next = 0;
+        float4 p = n_steps > 0 ? pack_step(pack, 0, n_pack, lane, n) : float4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < n_steps; s++) {
+            const float4 p_next = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);
+            const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;      // the operation order of every other distance here
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const uint32_t u = __float_as_uint(d2);
+            if (lane < n && d2 < lim && (u & pmask) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255u], 1u);
+            p = p_next; n = n_next;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // lane l owns bins 4l .. 4l + 3: the bin holding the want-th entry
+        const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+        const uint32_t sum = h0 + h1 + h2 + h3;
+        uint32_t incl = sum;
+        for (int off = 1; off < WAVE; off <<= 1) {
+            const uint32_t v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        const uint32_t all = __shfl(incl, WAVE - 1);
+        if (pass == 3) {
+            *total = (int)all;
+            if ((int)all < k) return 0u;
+        }
+        const uint32_t excl = incl - sum;
+        const bool mine = (uint32_t)want > excl && (uint32_t)want <= incl;      // exactly one lane
+        uint32_t b = 0, bl = 0;
+        if (mine) {
+            const uint32_t w = (uint32_t)want - excl;
+            if (w <= h0) { b = 0; bl = excl; }
+            else if (w <= h0 + h1) { b = 1; bl = excl + h0; }
+            else if (w <= h0 + h1 + h2) { b = 2; bl = excl + h0 + h1; }
+            else { b = 3; bl = excl + h0 + h1 + h2; }
+            b += 4 * lane;
+        }
+        const int src = __builtin_ctzll(__ballot(mine));
+        const uint32_t bin = __shfl(b, src);
+        want -= (int)__shfl(bl, src);
+        prefix |= bin << (8 * pass);
+        pmask |= 255u << (8 * pass);
+        __builtin_amdgcn_wave_barrier();
+    }
+    return prefix;
+}
+
+// ---- the three passes over the packed list (see rt_gather_tile.hip.h for the arithmetic they share)
+__device__ __forceinline__ void s_stage_put(float* st, const float4& p, int lane, int n)
+{
+    __builtin_amdgcn_wave_barrier();       // (the reads of the step before are done: LDS operations of a wave complete in order)
+    st[lane] = lane < n ? p.x : 1.0e18f; st[WAVE + lane] = p.y; st[2 * WAVE + lane] = p.z;
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ Xyz4 s_quad_load(const float* st, int j)
+{
+    return Xyz4{*reinterpret_cast<const float4*>(st + j), *reinterpret_cast<const float4*>(st + WAVE + j), *reinterpret_cast<const float4*>(st + 2 * WAVE + j)};
+}
+
+template <bool any_radius>
+__device__ __attribute__((noinline)) void stream_hist(const float4* pack, int n_pack, float qx, float qy, float qz, Shell sh, float radius2)
+{
+    uint32_t* const cell = g_S.table;
+    float* const st = g_S.stage;
+    const int lane = lane_id();
+#pragma unroll 8
+    for (int b = 0; b < T_BINS / 2; b++) cell[b * WAVE + lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    n_pack = __builtin_amdgcn_readfirstlane(n_pack);
+    const int n_steps = (n_pack + WAVE - 1) / WAVE;
+    uint32_t* const mine = hist_mine(cell, lane);
+    const uint32_t unit = hist_unit(lane);
+    int n = 0, n_next = 0;
+    float4 p = n_steps > 0 ? pack_step(pack, 0, n_pack, lane, n) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_steps; s++, n = n_next) {
+        s_stage_put(st, p, lane, n);
+        const int n_now = __builtin_amdgcn_readfirstlane(n);
+        p = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);      // on its way while this step is binned
+        auto bin4 = [&](const Xyz4& c) {
+            const D2x4 d = quad_d2(c, qx, qy, qz);
+            const f2 at_a = shell_pos(d.a, sh), at_b = shell_pos(d.b, sh);
+            int b0 = shell_bin_of(at_a.x), b1 = shell_bin_of(at_a.y), b2 = shell_bin_of(at_b.x), b3 = shell_bin_of(at_b.y);
+            if (any_radius) {
+                b0 = d.a.x < radius2 ? b0 : T_BINS - 1; b1 = d.a.y < radius2 ? b1 : T_BINS - 1;
+                b2 = d.b.x < radius2 ? b2 : T_BINS - 1; b3 = d.b.y < radius2 ? b3 : T_BINS - 1;
+            }
+            hist_add(mine, unit, b0);
+            hist_add(mine, unit, b1);
+            hist_add(mine, unit, b2);
+            hist_add(mine, unit, b3);
+        };
+        Xyz4 c0 = s_quad_load(st, 0), c1;
+        for (int j0 = 0; j0 < n_now; j0 += 8) {
+            c1 = s_quad_load(st, j0 + 4);
+            bin4(c0);
+            c0 = s_quad_load(st, (j0 + 8) & (WAVE - 1));
+            if (j0 + 4 < n_now) bin4(c1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool any_radius>
+__device__ __attribute__((noinline)) int stream_crit(const float4* pack, int n_pack, float qx, float qy, float qz, Shell sh, float radius2, int crit)
+{
+    uint32_t* const cell = g_S.table;
+    float* const st = g_S.stage;
+    const int lane = lane_id();
+    int cnt = 0;
+    n_pack = __builtin_amdgcn_readfirstlane(n_pack);
+    const int n_steps = (n_pack + WAVE - 1) / WAVE;
+    // (bin membership by one unsigned comparison: see pass_crit)
+    const float crit_f = crit >= 1 ? (float)crit : 1.0e30f;
+    const f2 crit_2 = {crit_f, crit_f};
+    constexpr uint32_t ONE = 0x3F800000u;
+    int n = 0, n_next = 0;
+    float4 p = n_steps > 0 ? pack_step(pack, 0, n_pack, lane, n) : float4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < n_steps; s++, n = n_next) {
+        s_stage_put(st, p, lane, n);
+        const int n_now = __builtin_amdgcn_readfirstlane(n);
+        p = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);
+        auto pick4 = [&](const Xyz4& c) {
+            const D2x4 d = quad_d2(c, qx, qy, qz);
+            const f2 at_a = shell_pos(d.a, sh), at_b = shell_pos(d.b, sh);
+            const f2 t_a = at_a - crit_2, t_b = at_b - crit_2;
+            uint32_t u0 = __float_as_uint(t_a.x), u1 = __float_as_uint(t_a.y), u2 = __float_as_uint(t_b.x), u3 = __float_as_uint(t_b.y);
+            if (any_radius) {      // (what the histogram put into the last bin is not in this one)
+                u0 = d.a.x < radius2 ? u0 : ONE; u1 = d.a.y < radius2 ? u1 : ONE; u2 = d.b.x < radius2 ? u2 : ONE; u3 = d.b.y < radius2 ? u3 : ONE;
+            }
+            const uint32_t least = min(min(u0, u1), min(u2, u3));
+            if (__ballot(least < ONE)) {           // rare: a few dozen photons per request
+                if (u0 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.x); cnt++; }
+                if (u1 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.a.y); cnt++; }
+                if (u2 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.x); cnt++; }
+                if (u3 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.y); cnt++; }
+            }
+        };
+        Xyz4 c0 = s_quad_load(st, 0), c1;
+        for (int j0 = 0; j0 < n_now; j0 += 8) {
+            c1 = s_quad_load(st, j0 + 4);
+            pick4(c0);
+            c0 = s_quad_load(st, (j0 + 8) & (WAVE - 1));
+            if (j0 + 4 < n_now) pick4(c1);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return cnt;
+}
+
+// the sums of main.cpp:262-291 over the photons with d2 <= t_k (see pass_sum)
+__device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_pack, const float* __restrict__ aux, float qx, float qy, float qz, float t_k, bool some,
+                                                     float nx, float ny, float nz)
+{
+    float* const st = g_S.stage;
+    float* const sa = g_S.stage + 3 * WAVE;
+    const int lane = lane_id();
+    const TermCoef tc = term_coef(t_k);
+    double s0 = 0, s1 = 0, s2 = 0;
+    n_pack = __builtin_amdgcn_readfirstlane(n_pack);
+    const int n_steps = (n_pack + WAVE - 1) / WAVE;
+    const float lim = some ? t_k : -1.f;
+    int n = 0, n_next = 0;
+    float4 p = float4{0.f, 0.f, 0.f, 0.f};
+    float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
+    if (n_steps > 0) {
+        p = pack_step(pack, 0, n_pack, lane, n);
+        const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)__float_as_uint(p.w);
+        b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
+    }
+    for (int s = 0; s < n_steps; s++, n = n_next) {
+        s_stage_put(st, p, lane, n);
+        {
+            sa[lane] = b0; sa[WAVE + lane] = b1; sa[2 * WAVE + lane] = b2; sa[3 * WAVE + lane] = b3; sa[4 * WAVE + lane] = b4; sa[5 * WAVE + lane] = b5;
+            __builtin_amdgcn_wave_barrier();
+        }
+        const int n_now = __builtin_amdgcn_readfirstlane(n);
+        {      // the next step's photons, power and direction are on their way while this step's are used
+            p = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);
+            const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)__float_as_uint(p.w);
+            b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
+        }
+        struct Aux4 { float4 pr, pg, pb, ux, uy, uz; };
+        auto aux_load = [&](int j) {
+            return Aux4{*reinterpret_cast<const float4*>(sa + j), *reinterpret_cast<const float4*>(sa + WAVE + j), *reinterpret_cast<const float4*>(sa + 2 * WAVE + j),
+                        *reinterpret_cast<const float4*>(sa + 3 * WAVE + j), *reinterpret_cast<const float4*>(sa + 4 * WAVE + j), *reinterpret_cast<const float4*>(sa + 5 * WAVE + j)};
+        };
+        auto sum4 = [&](const Xyz4& c, const Aux4& a) {
+            const D2x4 d = quad_d2(c, qx, qy, qz);
+            const float4 &pr4 = a.pr, &pg4 = a.pg, &pb4 = a.pb, &ux4 = a.ux, &uy4 = a.uy, &uz4 = a.uz;
+            // four photons at a time without a branch per photon: one outside the lane's ball contributes a factor 0;
+            // the four terms of a channel are added in float before they join the double sum
+            const bool in0 = d.a.x <= lim, in1 = d.a.y <= lim, in2 = d.b.x <= lim, in3 = d.b.y <= lim;
+            if (__ballot(in0 || in1 || in2 || in3)) {
+                const f2 c2 = {tc.c2, tc.c2}, A = {tc.A, tc.A}, B = {tc.B, tc.B};
+                const f2 ea = c2 * d.a, eb = c2 * d.b;
+                const f2 wa = A + B * f2{__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)}, wb = A + B * f2{__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)};
+                const f2 n_x = {nx, nx}, n_y = {ny, ny}, n_z = {nz, nz};
+                const f2 ca = n_x * f2{ux4.x, ux4.y} + n_y * f2{uy4.x, uy4.y} + n_z * f2{uz4.x, uz4.y};
+                const f2 cb = n_x * f2{ux4.z, ux4.w} + n_y * f2{uy4.z, uy4.w} + n_z * f2{uz4.z, uz4.w};
+                const float sc0 = in0 ? fabsf(ca.x) * wa.x : 0.f, sc1 = in1 ? fabsf(ca.y) * wa.y : 0.f;
+                const float sc2 = in2 ? fabsf(cb.x) * wb.x : 0.f, sc3 = in3 ? fabsf(cb.y) * wb.y : 0.f;
+                const f2 sa2 = {sc0, sc1}, sb2 = {sc2, sc3};
+                const f2 r = f2{pr4.x, pr4.y} * sa2 + f2{pr4.z, pr4.w} * sb2, g = f2{pg4.x, pg4.y} * sa2 + f2{pg4.z, pg4.w} * sb2, b = f2{pb4.x, pb4.y} * sa2 + f2{pb4.z, pb4.w} * sb2;
+                s0 += (double)(r.x + r.y);                   // main.cpp:286 without the hit colour, which the caller multiplies in
+                s1 += (double)(g.x + g.y);
+                s2 += (double)(b.x + b.y);
+            }
+        };
+        Xyz4 c0 = s_quad_load(st, 0), c1;
+        Aux4 a0 = aux_load(0), a1;
+        for (int j0 = 0; j0 < n_now; j0 += 8) {
+            c1 = s_quad_load(st, j0 + 4); a1 = aux_load(j0 + 4);
+            sum4(c0, a0);
+            c0 = s_quad_load(st, (j0 + 8) & (WAVE - 1)); a0 = aux_load((j0 + 8) & (WAVE - 1));
+            if (j0 + 4 < n_now) sum4(c1, a1);
+        }
+    }
+    return Sum3{s0, s1, s2};
+}
+
+// Slots of the cycle accounting that mean something else here than in gather_tile_kernel: TP_KTH = walk + packing + the
+// centre's radix passes of all attempts, TP_WALK = the in-place filter, TP_N_HIST = attempts, TP_N_CRIT = photons packed
+// by the last attempt, TP_N_SUM = photons streamed by the passes.
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void gather_stream_kernel(PhotonMapView pm, TileArgs ta, GatherParams gp, double* __restrict__ acc,
+                                                                                                         float4* pack_all)
+{
+    uint32_t* const cell = g_S.table;
+    const int lane = lane_id();
+    float4* const pack = pack_all + (size_t)blockIdx.x * S_PACK_CAP;
+    const rtq::Map map = rtq::map_units(ta.cnt, ta.shard_cap, WAVE);
+    const uint32_t n_windows = map.total;
+    if (lane == 0) atomicAdd(ta.windows_done + 1, 1ull);
+    unsigned long long pr[TP_SLOTS] = {};
+    const unsigned long long t_begin = ta.prof ? clock64() : 0ull;
+    const float r_max = sqrtf(gp.r2);
+    float prev_r = -1.f;                 // the last centre's k-th distance: the next guess
+#define TILE_PROF(slot, expr) do { if (ta.prof) { const unsigned long long t_ = clock64(); expr; pr[slot] += clock64() - t_; } else { expr; } } while (0)
+#define TILE_COUNT(slot, cond) do { if (ta.prof) pr[slot] += __builtin_popcountll(__ballot(cond)); } while (0)
+    while (true) {
+        unsigned long long w0 = 0;
+        if (lane == 0) w0 = atomicAdd(ta.next, 1ull);
+        const uint32_t win = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)w0);
+        const uint32_t win_hi = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(w0 >> 32));
+        if (win_hi || win >= n_windows) break;       // (the high half is zero for any real queue)
+        unsigned shard;
+        uint32_t first, n_shard;
+        rtq::locate(map, win, WAVE, shard, first, n_shard);
+        const unsigned long long slot0 = (unsigned long long)shard * ta.shard_cap + first;
+        const int n_req = (int)((ta.recs[slot0].flags >> GATHER_COUNT_SHIFT) & 127u);
+        const bool have = lane < n_req;
+        const GatherRec& r = ta.recs[slot0 + (have ? lane : 0)];
+        const float qx = (float)r.pos[0], qy = (float)r.pos[1], qz = (float)r.pos[2];
+        const uint32_t flags = r.flags & 0xFFu;
+        // Subsurface requests: their surface estimate is one of four gathers (main.cpp:260-388) and the only one in this
+        // map; it is formed here with the group's, written into the record, and the request handed on for the rest.
+        const bool sss = (flags & GATHER_SSS) != 0;
+        bool redo = have && ((flags & ~(GATHER_SSS | GATHER_MARCH)) != 0 || (sss && !ta.sss_surface) || ta.all_redo || pm.n >= (1ll << 24));
+        bool todo = have && !redo;
+        pr[TP_WINDOWS]++;
+        TILE_COUNT(TP_R_FLAGS, redo);
+        // A window mostly holds one patch of neighbouring hit points, but it may hold a few (a tile across a silhouette):
+        // each round takes the requests close to one of those still waiting; what is left after the last round, and
+        // rounds of only a few requests, go to the per-request kernel.
+        const int ROUNDS = gp.max_rounds;
+        const int MIN_LANES = gp.min_lanes > 0 ? gp.min_lanes : (gp.k >= 400 ? 12 : 6);
+        for (int round = 0; round < ROUNDS; round++) {
+            const unsigned long long m_todo = __ballot(todo);
+            if (!m_todo) break;
+            // ---- the round's centre: the middle one of the requests waiting
+            int c_lane = 0;
+            {
+                const int want_rank = __builtin_popcountll(m_todo) / 2;
+                unsigned long long mm = m_todo;
+                for (int i = 0; i < want_rank; i++) mm &= mm - 1;
+                c_lane = __builtin_ctzll(mm);
+            }
+            const float cx = bcast(qx, c_lane), cy = bcast(qy, c_lane), cz = bcast(qz, c_lane);
+            const float ddx = qx - cx, ddy = qy - cy, ddz = qz - cz;
+            const float d_c = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            // a first look at who is near, with the radius unknown: if only a few are within the widest possible ball they
+            // are not worth a round of their own
+            const bool near = todo && d_c <= r_max;
+            if (__builtin_popcountll(__ballot(near)) < MIN_LANES) {
+                TILE_COUNT(TP_R_FEW, near);
+                redo = redo || near;
+                todo = todo && !near;
+                continue;
+            }
+            // ---- 1. the centre's k-th distance r_c (< 0: fewer than k photons within the search radius)
+            float r_c = -1.f;
+            int n_pack = 0;
+            bool found = false;
+            {
+                const unsigned long long t_kth = ta.prof ? clock64() : 0ull;
+                float guess = prev_r > 0.f ? prev_r * 1.2f : r_max * 0.3f;
+                float too_small = 0.f, too_large = 3.0e38f;      // guesses that held fewer than k photons / overflowed the lists
+                for (int attempt = 0; attempt < S_ATTEMPTS && !found; attempt++) {
+                    pr[TP_N_HIST]++;
+                    const float R = fminf(guess, r_max);
+                    const bool whole = !(R < r_max);                            // the search radius itself: nothing larger to try
+                    const bool cand = near && d_c <= R;                         // who can be in the round if r_c <= R
+                    // every such request's ball lies within its point +- rad (its bound never exceeds the search radius)
+                    const float rad = fminf(R * (1.f + gp.opt_range) * 1.002f + 1e-5f, r_max * 1.0002f + 2e-6f);
+                    const float big = 3.0e38f;
+                    const float glx = wave_min_f(cand ? qx - rad : big), gly = wave_min_f(cand ? qy - rad : big), glz = wave_min_f(cand ? qz - rad : big);
+                    const float ghx = wave_max_f(cand ? qx + rad : -big), ghy = wave_max_f(cand ? qy + rad : -big), ghz = wave_max_f(cand ? qz + rad : -big);
+                    const float reach = wave_max_f(cand ? d_c : 0.f) + rad;
+                    __builtin_amdgcn_wave_barrier();
+                    const int lists = stream_walk(pm, glx, gly, glz, ghx, ghy, ghz);
+                    int packed = -1;
+                    if (lists >= 0) {
+                        const int n_leaf = lists & 0xFFFF, n_piv = lists >> 16;
+                        rank_sort(g_S.w.leaf, g_S.w.leaf_sorted, n_leaf);
+                        rank_sort(g_S.w.piv, g_S.w.piv_sorted, n_piv);
+                        __builtin_amdgcn_wave_barrier();
+                        packed = pack_listed(pm.pos, pack, cx, cy, cz, reach * reach * 1.0001f, n_leaf, n_piv);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (packed < 0) {
+                        // too much of the tree: a smaller radius, unless that is known to hold fewer than k photons
+                        too_large = R;
+                        guess = fmaxf(R * 0.6f, sqrtf(too_small * R));
+                        if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
+                        continue;
+                    }
+                    int total = 0;
+                    const uint32_t bits = centre_kth(pack, packed, cx, cy, cz, whole ? gp.r2 : R * R, gp.k, &total);
+                    __builtin_amdgcn_wave_barrier();
+                    if (total >= gp.k) { r_c = sqrtf(__uint_as_float(bits)); n_pack = packed; found = true; }
+                    else if (whole) { r_c = -1.f; n_pack = packed; found = true; }      // fewer than k within the search radius
+                    else {
+                        too_small = R;
+                        guess = fminf(R * 1.4f, too_large < 3.0e38f ? sqrtf(R * too_large) : 3.0e38f);
+                        if (guess >= too_large * 0.98f || guess <= R * 1.02f) break;
+                    }
+                }
+                if (ta.prof) pr[TP_KTH] += clock64() - t_kth;
+            }
+            if (!found) {      // the lists cannot hold what the centre's ball touches
+                TILE_COUNT(TP_R_WALK, near);
+                redo = redo || near;
+                todo = todo && !near;
+                continue;
+            }
+            bool act = near;
+            float bound = gp.r2, lower = 0.f;
+            if (r_c >= 0.f) {
+                prev_r = r_c;
+                act = todo && d_c <= r_c;                            // this round: the requests inside the centre's own ball
+                // r_k(q) lies within |q - q_c| of r_c (triangle inequality).  For a request far from the centre that
+                // range is wide while the photon density, and with it r_k, changes little over a ball's width: such a
+                // request is given the range r_c * (1 -+ opt_range) instead.  Both ends are checked by the counts below
+                // (k photons inside the outer radius, fewer than k inside the inner one); a request that fails either
+                // goes to the per-request kernel.
+                const float dd = fminf(d_c, gp.opt_range * r_c);
+                const float reach = r_c + dd;
+                const float b = reach * reach * 1.001f + 1e-12f;      // slack for the rounding of the distances
+                if (b < bound) {
+                    bound = b;
+                    // and r_k(q) >= r_c - |q - q_c|: closer photons belong to the set whatever their order
+                    const float inner = fmaxf(r_c - dd, 0.f);
+                    lower = inner * inner * 0.999f;
+                }
+            }
+            if (__builtin_popcountll(__ballot(act)) < MIN_LANES) {
+                // (the centre itself is always among them, so every round retires at least one request)
+                TILE_COUNT(TP_R_FEW, act);
+                redo = redo || act;
+                todo = todo && !act;
+                continue;
+            }
+            todo = todo && !act;
+            // ---- 2. the packed list cut down to the box around the round's balls and the centre's reach: what it holds now
+            // depends on the window alone
+            {
+                const float rad = act ? sqrtf(bound) * 1.0001f + 1e-6f : 0.f;
+                const float big = 3.0e38f;
+                Box6f bx;
+                bx.lx = wave_min_f(act ? qx - rad : big); bx.ly = wave_min_f(act ? qy - rad : big); bx.lz = wave_min_f(act ? qz - rad : big);
+                bx.hx = wave_max_f(act ? qx + rad : -big); bx.hy = wave_max_f(act ? qy + rad : -big); bx.hz = wave_max_f(act ? qz + rad : -big);
+                const float reach = wave_max_f(act ? d_c + rad : 0.f);
+                pr[TP_N_CRIT] += n_pack;
+                TILE_PROF(TP_WALK, n_pack = pack_refilter(pack, n_pack, cx, cy, cz, reach * reach * 1.0001f, bx));
+                __builtin_amdgcn_wave_barrier();
+            }
+            const int n_steps = (n_pack + WAVE - 1) / WAVE;
+            pr[TP_ROUNDS]++; pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_steps; pr[TP_N_SUM] += n_pack;
+
+            const Shell sh = shell_of(bound, lower);
+            const float radius2 = act && !(bound < gp.r2) ? gp.r2 : 3.0e38f;      // lanes bounded by the search radius itself
+            const bool any_radius = __ballot(radius2 < 3.0e38f) != 0;
+            // ---- 3a. per-lane histogram of the squared distances below the lane's bound
+            if (any_radius) TILE_PROF(TP_HIST, stream_hist<true>(pack, n_pack, qx, qy, qz, sh, radius2));
+            else TILE_PROF(TP_HIST, stream_hist<false>(pack, n_pack, qx, qy, qz, sh, radius2));
+            uint32_t* const mine = hist_mine(cell, lane);
+            // the bin holding the lane's k-th smallest distance (or its largest, if fewer than k lie within the bound)
+            uint32_t total = 0;                                   // (the last bin holds what lies beyond the bound)
+#pragma unroll 4
+            for (int b = 0; b < T_BINS - 1; b++) total += hist_count(mine, lane, b);
+            const uint32_t k_eff = total < (uint32_t)gp.k ? total : (uint32_t)gp.k;
+            // a bound derived from the neighbour must contain k photons; if it does not, the per-request kernel decides
+            TILE_COUNT(TP_R_SHORT, act && total < (uint32_t)gp.k && bound < gp.r2);
+            if (act && total < (uint32_t)gp.k && bound < gp.r2) { redo = true; act = false; }
+            int crit = -1;
+            uint32_t below = 0, in_bin = 0;
+            {
+                uint32_t cum = 0;
+#pragma unroll 4
+                for (int b = 0; b < T_BINS - 1; b++) {
+                    const uint32_t h = hist_count(mine, lane, b);
+                    if (crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
+                    cum += h;
+                }
+            }
+            // (k photons already inside the inner radius: the range was guessed too high -- the rigorous range never is)
+            const bool crowded = act && k_eff > 0 && (in_bin > (uint32_t)T_CRIT || crit == 0);
+            TILE_COUNT(TP_R_CROWD, crowded);
+            if (crowded) { redo = true; act = false; }
+            const bool some = act && k_eff > 0;
+            const int need = (int)(k_eff - below);                 // 1-based rank of the k-th smallest inside its bin
+            __builtin_amdgcn_wave_barrier();
+            // ---- 3b. the distances of that bin, ranked
+            int cnt;
+            if (any_radius) TILE_PROF(TP_CRIT, cnt = stream_crit<true>(pack, n_pack, qx, qy, qz, sh, radius2, some ? crit : -1));
+            else TILE_PROF(TP_CRIT, cnt = stream_crit<false>(pack, n_pack, qx, qy, qz, sh, radius2, some ? crit : -1));
+            const unsigned long long t_rank = ta.prof ? clock64() : 0ull;
+            const int max_cnt = (int)wave_max_f((float)cnt);
+            uint32_t t_bits = 0;
+            for (int i0 = 0; i0 < max_cnt; i0 += 8) {
+                // eight entries in registers per sweep over the lane's column
+                uint32_t e[8];
+                int rank[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { e[u] = cell[(i0 + u < T_CRIT ? i0 + u : T_CRIT - 1) * WAVE + lane]; rank[u] = 0; }
+#pragma unroll 4
+                for (int j = 0; j < max_cnt; j++) {
+                    const uint32_t o = cell[j * WAVE + lane];
+                    const bool in_col = j < cnt;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) rank[u] += (in_col && (o < e[u] || (o == e[u] && j < i0 + u))) ? 1 : 0;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (i0 + u < cnt && rank[u] == need - 1) t_bits = e[u];
+            }
+            int less = 0, equal = 0;
+            for (int j = 0; j < max_cnt; j++) {
+                const uint32_t o = cell[j * WAVE + lane];
+                less += (j < cnt && o < t_bits) ? 1 : 0;
+                equal += (j < cnt && o == t_bits) ? 1 : 0;
+            }
+            const float t_k = __uint_as_float(t_bits);             // the k-th distance = maxDistSqr (main.cpp:266-267)
+            const int want_eq = need - less;                       // photons at exactly that distance that belong to the set
+            // Several photons at exactly the k-th distance of which only some belong: the per-request kernel decides which
+            // (it has a rule that does not depend on the order the photons are met in); here every one at that distance counts.
+            const bool split_tie = some && equal != want_eq;
+            TILE_COUNT(TP_R_TIE, split_tie);
+            if (split_tie) redo = true;
+            const bool summed = some && !split_tie;
+            __builtin_amdgcn_wave_barrier();
+            if (ta.prof) pr[TP_RANK] += clock64() - t_rank;
+            // ---- 3c. the estimate over the set (main.cpp:262-295)
+            Sum3 sum;
+            TILE_PROF(TP_SUM, sum = stream_sum(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2]));
+            if (summed) {
+                const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
+                double rgb[3] = {r.color[0] * sum.s0 * sc, r.color[1] * sum.s1 * sc, r.color[2] * sum.s2 * sc};
+                if (sss) {
+                    GatherRec* const w = const_cast<GatherRec*>(&r);
+                    w->normal[0] = rgb[0]; w->normal[1] = rgb[1]; w->normal[2] = rgb[2];
+                    w->flags = r.flags | GATHER_SURFACE_DONE;
+                    redo = true;
+                } else {
+                    clip3(rgb);                                    // main.cpp:391
+                    for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        TILE_COUNT(TP_R_LEFT, todo);
+        redo = redo || todo;
+        // ---- requests left to the per-request kernel
+        const unsigned long long m_redo = __ballot(redo);
+        if (m_redo) {
+            unsigned long long at = 0;
+            const int leader = __builtin_ctzll(m_redo);
+            if (lane == leader) at = atomicAdd(ta.n_redo, (unsigned long long)__builtin_popcountll(m_redo));
+            at = ((unsigned long long)(unsigned)__shfl((unsigned)(at >> 32), leader) << 32) | (unsigned)__shfl((unsigned)at, leader);
+            if (redo) __hip_atomic_store(&ta.redo[at + prefix_rank(m_redo)], (uint32_t)(slot0 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __threadfence();                                        // the entries are visible before the window counts as done
+        if (lane == 0) atomicAdd(ta.windows_done, 1ull);
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef TILE_PROF
+#undef TILE_COUNT
+    if (ta.prof && lane == 0) {
+        pr[TP_BUSY] = clock64() - t_begin;
+        for (int i = 0; i < TP_BUSY_MAX; i++) atomicAdd(&ta.prof[i], pr[i]);
+        atomicMax(&ta.prof[TP_BUSY_MAX], pr[TP_BUSY]);
+    }
+}
+
+}  // namespace rtg
