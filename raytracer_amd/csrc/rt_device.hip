@@ -18,6 +18,7 @@
 #include "host_scene.h"
 #include "rt_flat.h"
 #include "rt_gather_tile.hip.h"
+#include "rt_gather_stream.hip.h"
 #include "rt_kernels.hip.h"
 #include "rt_math.h"
 #include "rt_emit.hip.h"
@@ -103,12 +104,16 @@ int upload_n(DevBuf& b, const T* v, size_t n, hipStream_t s)
 
 // ---- working memory of the entry point that allocates nothing (rt_knn_estimate_dev_noalloc) -----------------------
 // One fixed array per GPU the library runs on, held until the process ends: [counter block + overflow latch]
-// [request queue: RT_NOALLOC_MAX_REQUESTS records] [list of the requests the group kernel hands on].
+// [request queue: RT_NOALLOC_MAX_REQUESTS records] [list of the requests the group kernel hands on] [packed photon
+// lists of NA_PACK_WAVES waves].
 constexpr size_t NA_COUNTERS = rtk::LATCH_OFFSET + 256;
 constexpr size_t NA_QUEUE = (size_t)RT_NOALLOC_MAX_REQUESTS * sizeof(rtg::GatherRec);
 constexpr size_t NA_REDO = (size_t)RT_NOALLOC_MAX_REQUESTS * sizeof(uint32_t);
+constexpr int NA_PACK_WAVES = 512;      // waves of the group kernel this entry point launches: each needs a packed photon list
+constexpr size_t NA_PACK = (size_t)NA_PACK_WAVES * rtg::S_PACK_CAP * sizeof(float4);
 static_assert(RT_NOALLOC_MAX_REQUESTS % 64 == 0 && NA_QUEUE % 256 == 0, "the queue is whole windows and the list behind it stays aligned");
-static __device__ __align__(256) unsigned char scratch[NA_COUNTERS + NA_QUEUE + NA_REDO];
+static_assert(NA_REDO % 256 == 0, "the packed lists behind the hand-over list stay aligned");
+static __device__ __align__(256) unsigned char scratch[NA_COUNTERS + NA_QUEUE + NA_REDO + NA_PACK];
 // `scratch` is a host-side stand-in here, not a device address: host code uses the address hipGetSymbolAddress
 // gave for it on the device in question (every GPU holds its own copy of the array at its own address).
 constexpr int NA_MAX_DEVICES = 64;
@@ -156,6 +161,7 @@ struct rt_context {
     rtg::PhotonMapView pm[2] = {};
     // render queues
     DevBuf hits_a, hits_b, rays, gq, acc, redo;
+    DevBuf pack;              // packed photon lists of the group gather's waves (rtg::S_PACK_CAP entries each)
     // staging for the host-buffer convenience entry points
     DevBuf st_org, st_dir, st_dist, st_ids, st_aux;
 };
@@ -417,7 +423,7 @@ void rt_context_destroy(rt_context* ctx)
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->obj_live, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->ctr_log, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
-                      &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->redo, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
+                      &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->redo, &ctx->pack, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
                       &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1], &ctx->ph_box[0], &ctx->ph_box[1], &ctx->ph_src[0], &ctx->ph_src[1],
                       &ctx->ph_raw[0], &ctx->ph_raw[1], &ctx->kd_work})
         b->release();
@@ -1465,7 +1471,7 @@ int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const
 namespace {
 int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
                   unsigned long long* n_redo, unsigned long long* next_gather, unsigned long long* windows_done, const rtg::GatherParams& gp, double* d_acc,
-                  uint32_t* d_redo, size_t redo_entries, bool may_profile = true);
+                  uint32_t* d_redo, size_t redo_entries, bool may_profile = true, float4* d_pack = nullptr, int pack_waves = 0);
 int reserve_redo(rt_context* ctx, size_t entries);
 }
 extern "C" {
@@ -1576,7 +1582,7 @@ int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int6
     gp.photon_num = (double)p->photon_num;
     gp.seed = 12345u;
     rc = launch_gather(ctx, recs, &ctr->gather, (unsigned long long)slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, ctr->tile_progress, gp, d_rgb, redo,
-                       NA_REDO / sizeof(uint32_t), false);
+                       NA_REDO / sizeof(uint32_t), false, (float4*)(base + NA_COUNTERS + NA_QUEUE + NA_REDO), NA_PACK_WAVES);
     // (recorded even when a launch failed part-way: whatever did get enqueued uses the array)
     if (hipEventRecord(g_scratch_done[ctx->device], ctx->stream) == hipSuccess) g_scratch_used[ctx->device] = true;
     return rc;
@@ -1590,14 +1596,30 @@ namespace {
 // left.  RT_GATHER_MODE=query hands every request to the per-request kernel (comparison runs).
 int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
                   unsigned long long* n_redo, unsigned long long* next_gather, unsigned long long* windows_done, const rtg::GatherParams& gp, double* d_acc,
-                  uint32_t* d_redo, size_t redo_entries, bool may_profile)
+                  uint32_t* d_redo, size_t redo_entries, bool may_profile, float4* d_pack, int pack_waves)
 {
     const char* mode = getenv("RT_GATHER_MODE");
+    // RT_GATHER_FORM=tile: the earlier group kernel, which streams the listed leaves themselves (comparison runs)
+    const char* form = getenv("RT_GATHER_FORM");
+    const bool packed = !(form && form[0] == 't');
+    // the group kernel over packed lists: twelve waves per CU, each with a list of its own (the caller's, or the context's)
+    int tile_waves = ctx->num_cus * (packed ? 12 : 8);
+    if (const char* e = getenv("RT_GATHER_WAVES")) tile_waves = ctx->num_cus * std::max(1, std::min(12, atoi(e)));      // tuning aid: waves per CU
+    if (packed) {
+        if (!d_pack) {
+            int rc_p = ctx->pack.reserve((size_t)tile_waves * rtg::S_PACK_CAP * sizeof(float4));
+            if (rc_p) return rc_p;
+            d_pack = (float4*)ctx->pack.p;
+        } else {
+            tile_waves = std::min(tile_waves, pack_waves);
+        }
+    }
     // RT_GATHER_PROF=1: per-phase cycle totals of the group kernel, printed to stderr (development aid)
     const bool prof = may_profile && getenv("RT_GATHER_PROF") != nullptr;      // (the cycle accounting allocates its table)
     int rc;
     if (prof && (rc = ctx->st_aux.reserve(rtg::TP_SLOTS * 8))) return rc;
     if (prof) HIP_TRY(hipMemsetAsync(ctx->st_aux.p, 0, rtg::TP_SLOTS * 8, ctx->stream));
+    if (prof) HIP_TRY(hipMemsetAsync((unsigned long long*)ctx->st_aux.p + rtg::TP_W_FIRST_MIN, 0xFF, 8, ctx->stream));
     rtg::GatherParams gpt = gp;
     // The relative range around the centre's k-th distance searched for a neighbour's: it has to cover the scatter of a
     // k-th distance (about 1 / (2 sqrt(k)) of it) and the change of the photon density across a ball; what it misses
@@ -1613,7 +1635,9 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, windows_done, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
                      sss_scene ? 1 : 0, prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));      // (the queue and the counters are ready here)
-    hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc);
+    if (packed && prof) hipLaunchKernelGGL(rtg::gather_stream_prof_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc, d_pack);
+    else if (packed) hipLaunchKernelGGL(rtg::gather_stream_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc, d_pack);
+    else hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc);
     HIP_TRY(hipGetLastError());
     // The per-request kernel alongside, on the second stream.  Its waves stay only once every wave of the group kernel
     // has begun, so they never hold a place the group kernel waits for; six blocks per CU leave room for one of the
@@ -1621,7 +1645,7 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     if (!sss_scene) {
         HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         hipLaunchKernelGGL(rtg::gather_alongside_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->side, ctx->pm[0], ctx->pm[1], recs, d_redo,
-                           (uint32_t)std::min<size_t>(redo_entries, 0xFFFFFFFFu), cnt, shard_cap, (const unsigned long long*)windows_done, (unsigned)(ctx->num_cus * 8),
+                           (uint32_t)std::min<size_t>(redo_entries, 0xFFFFFFFFu), cnt, shard_cap, (const unsigned long long*)windows_done, (unsigned)tile_waves,
                            next_gather, gp, d_acc);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
@@ -1631,12 +1655,28 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
         HIP_TRY(hipMemcpyAsync(v, ctx->st_aux.p, sizeof v, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         const double nr = (double)std::max<unsigned long long>(1, v[rtg::TP_ROUNDS]);
+        if (packed)
+            fprintf(stderr, "packed group gather (k=%d): %llu windows, %llu rounds, %.1f requests per round, %.2f attempts at the centre's radius, %.0f photons packed for it, "
+                            "%.0f streamed by the passes (%.1f steps); cycles per round: walk + pack + centre %.0f, filter %.0f, hist %.0f, crit %.0f, rank %.0f, sum %.0f\n",
+                    gp.k, v[rtg::TP_WINDOWS], v[rtg::TP_ROUNDS], v[rtg::TP_LANES] / nr, v[rtg::TP_N_HIST] / nr, v[rtg::TP_N_CRIT] / nr, v[rtg::TP_N_SUM] / nr, v[rtg::TP_STEPS] / nr,
+                    v[rtg::TP_KTH] / nr, v[rtg::TP_WALK] / nr, v[rtg::TP_HIST] / nr, v[rtg::TP_CRIT] / nr, v[rtg::TP_RANK] / nr, v[rtg::TP_SUM] / nr);
+        if (packed)
+            fprintf(stderr, "  the centre's radius, cycles per round: guess %.0f, walks %.0f, counts %.0f, sort %.0f, packing %.0f, radix passes %.0f; attempts per round that ended in: "
+                            "no guess %.3f, lists too small %.3f, fewer than k %.3f, far more than k %.3f, packed list too small %.3f\n",
+                    v[rtg::TP_C_GUESS] / nr, v[rtg::TP_C_WALK] / nr, v[rtg::TP_C_COUNT] / nr, v[rtg::TP_C_SORT] / nr, v[rtg::TP_C_PACK] / nr, v[rtg::TP_C_KTH] / nr,
+                    v[rtg::TP_A_NOGUESS] / nr, v[rtg::TP_A_LISTS] / nr, v[rtg::TP_A_FEW] / nr, v[rtg::TP_A_MANY] / nr, v[rtg::TP_A_PACK] / nr);
+        if (packed)
+            fprintf(stderr, "  windows by rounds taken (<= 1, 2, 3, 4 and more): %llu / %llu / %llu / %llu, mean cycles %.0f / %.0f / %.0f / %.0f, longest window %llu; kernel span first wave's start to last wave's end %llu cycles\n",
+                    v[rtg::TP_W_ROUNDS1], v[rtg::TP_W_ROUNDS2], v[rtg::TP_W_ROUNDS3], v[rtg::TP_W_ROUNDS4],
+                    v[rtg::TP_W_CYC1] / (double)std::max<unsigned long long>(1, v[rtg::TP_W_ROUNDS1]), v[rtg::TP_W_CYC2] / (double)std::max<unsigned long long>(1, v[rtg::TP_W_ROUNDS2]),
+                    v[rtg::TP_W_CYC3] / (double)std::max<unsigned long long>(1, v[rtg::TP_W_ROUNDS3]), v[rtg::TP_W_CYC4] / (double)std::max<unsigned long long>(1, v[rtg::TP_W_ROUNDS4]),
+                    v[rtg::TP_W_MAX], v[rtg::TP_W_LAST_MAX] - v[rtg::TP_W_FIRST_MIN]);
         fprintf(stderr, "group gather (k=%d): %llu windows, %llu rounds, %.1f requests and %.1f steps of 64 photons per round (hist %.1f, crit %.1f, sum %.1f steps); "
                         "cycles per round: kth %.0f, walk %.0f, hist %.0f, crit %.0f, rank %.0f, sum %.0f; requests handed on: %llu other materials, %llu in small rounds, "
                         "%llu box too large, %llu range too low, %llu range too high or crowded bin, %llu left after the last round, %llu ties to split; busy cycles per wave: mean %.0f, longest %llu\n",
                 gp.k, v[rtg::TP_WINDOWS], v[rtg::TP_ROUNDS], v[rtg::TP_LANES] / nr, v[rtg::TP_STEPS] / nr, v[rtg::TP_N_HIST] / nr, v[rtg::TP_N_CRIT] / nr, v[rtg::TP_N_SUM] / nr,
                 v[rtg::TP_KTH] / nr, v[rtg::TP_WALK] / nr, v[rtg::TP_HIST] / nr, v[rtg::TP_CRIT] / nr, v[rtg::TP_RANK] / nr, v[rtg::TP_SUM] / nr, v[rtg::TP_R_FLAGS],
-                v[rtg::TP_R_FEW], v[rtg::TP_R_WALK], v[rtg::TP_R_SHORT], v[rtg::TP_R_CROWD], v[rtg::TP_R_LEFT], v[rtg::TP_R_TIE], v[rtg::TP_BUSY] / (ctx->num_cus * 8.0), v[rtg::TP_BUSY_MAX]);
+                v[rtg::TP_R_FEW], v[rtg::TP_R_WALK], v[rtg::TP_R_SHORT], v[rtg::TP_R_CROWD], v[rtg::TP_R_LEFT], v[rtg::TP_R_TIE], v[rtg::TP_BUSY] / (double)tile_waves, v[rtg::TP_BUSY_MAX]);
     }
     hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, d_redo,
                        (const unsigned long long*)n_redo, next_gather, gp, d_acc);

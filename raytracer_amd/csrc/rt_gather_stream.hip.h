@@ -35,6 +35,8 @@ namespace rtg {
 
 constexpr int S_PACK_CAP = 4096;      // photons the packed list of a wave holds (16 bytes each)
 constexpr int S_ATTEMPTS = 7;         // guesses at the centre's radius per round before the round is handed on
+constexpr int S_FLIGHT = 8;           // 64-photon steps of a streaming loop whose loads are in flight together
+constexpr int S_CELL = 512;           // photons in the tree cell whose density gives the first guess
 
 // Per-wave LDS of the kernel: 12.5 KB, so that twelve waves share a CU.  The per-lane tables of the passes lie over
 // what the walk and the sort of its lists need, which is dead once the packed list exists.
@@ -52,11 +54,13 @@ struct StreamLds {
 static_assert(T_CRIT * WAVE <= (T_BINS / 2) * WAVE && sizeof(StreamLds) <= 13 * 1024, "twelve waves per CU");
 __shared__ StreamLds g_S;
 
-typedef float4 __attribute__((address_space(1))) gfloat4;
+// 16 bytes read as GLOBAL memory (a pointer of unknown address space makes it a flat load, which every wait for an LDS
+// read in the loops would wait for, too)
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load_global4(const float4* p)
 {
-    const gfloat4* g = (const gfloat4*)p;
-    return *g;
+    const v4f v = *(const v4f __attribute__((address_space(1)))*)p;
+    return float4{v.x, v.y, v.z, v.w};
 }
 
 // ---- the walk: leaves and pivots inside the box [gl, gh] -> g_S.w.leaf / piv; n_leaf | n_piv << 16, or -1 when the
@@ -122,45 +126,17 @@ __device__ __forceinline__ void rank_sort(const uint32_t* src, uint32_t* dst, in
     }
 }
 
-// Step s of the sorted lists: lane j's tree position (clamped to a valid one) and the photons in the step.
-__device__ __forceinline__ int list_step(int s, int n_leaf, int n_piv, int lane, int& n)
+// Step s of a pair of lists (leaves, pivots): lane j's tree position (clamped to a valid one) and the photons in the step.
+__device__ __forceinline__ int list_step(const uint32_t* leaf, const uint32_t* piv, int s, int n_leaf, int n_piv, int lane, int& n)
 {
-    const StreamLds& S = g_S;
     if (s < n_leaf) {
-        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.w.leaf_sorted[s]);
+        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)leaf[s]);
         n = (int)(e & 127u);
         return (int)(e >> 7) + (lane < n ? lane : n - 1);
     }
     const int first = (s - n_leaf) * WAVE;
     n = n_piv - first < WAVE ? n_piv - first : WAVE;
-    return (int)S.w.piv_sorted[first + (lane < n ? lane : n - 1)];
-}
-
-// ---- packing, first stage: the photons of the listed leaves and pivots within sqrt(reach2) of the centre, in tree
-// order, as (x, y, z, tree position).  Returns their number, or -1 when they exceed the list.
-__device__ __attribute__((noinline)) int pack_listed(const float4* __restrict__ pos, float4* pack, float cx, float cy, float cz, float reach2, int n_leaf, int n_piv)
-{
-    const int lane = lane_id();
-    n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);
-    const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
-    int out = 0, n = 0, n_next = 0;
-    int at = n_steps > 0 ? list_step(0, n_leaf, n_piv, lane, n) : 0, at_next = 0;
-    float4 p = n_steps > 0 ? load_global4(pos + at) : float4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < n_steps; s++) {
-        // the next step's photons are on their way while this step's are filtered (the fetch is unconditional: one
-        // inside a branch is waited for at the branch's end)
-        at_next = list_step(s + 1 < n_steps ? s + 1 : s, n_leaf, n_piv, lane, n_next);
-        const float4 p_next = load_global4(pos + at_next);
-        const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
-        const bool keep = lane < n && dx * dx + dy * dy + dz * dz <= reach2;
-        const unsigned long long m = __ballot(keep);
-        const int c = __builtin_popcountll(m);
-        if (out + c > S_PACK_CAP) return -1;
-        if (keep) pack[out + (int)prefix_rank(m)] = float4{p.x, p.y, p.z, __uint_as_float((uint32_t)at)};
-        out += c;
-        p = p_next; at = at_next; n = n_next;
-    }
-    return out;
+    return (int)piv[first + (lane < n ? lane : n - 1)];
 }
 
 // a step of the packed list: lane j's entry (clamped) and the entries in the step
@@ -171,6 +147,127 @@ __device__ __forceinline__ float4 pack_step(const float4* pack, int s, int n_pac
     return load_global4(pack + first + (lane < n ? lane : n - 1));
 }
 
+// ---- packing, first stage: the photons of the listed leaves and pivots within sqrt(reach2) of the centre, in tree
+// order, as (x, y, z, tree position).  Returns their number, or -1 when they exceed the list.
+// On the way, the photons within sqrt(lim) of the centre (strictly) are counted into *inside and their squared distances
+// binned into 256 linear bins over [0, lim) (C_HIST words of the staging area).
+constexpr int C_BINS = 256;
+__device__ __forceinline__ uint32_t* centre_hist() { return reinterpret_cast<uint32_t*>(g_S.stage); }
+__device__ __forceinline__ int centre_bin(float d2, float hscale) { const int b = (int)(d2 * hscale); return b < C_BINS - 1 ? b : C_BINS - 1; }
+__device__ __attribute__((noinline)) int pack_listed(const float4* __restrict__ pos, float4* pack, float cx, float cy, float cz, float reach2, float lim, int n_leaf, int n_piv,
+                                                     int* inside)
+{
+    const int lane = lane_id();
+    uint32_t* const hist = centre_hist();
+    for (int b = lane; b < C_BINS; b += WAVE) hist[b] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const float hscale = (float)C_BINS / lim;
+    int count = 0;
+    n_leaf = __builtin_amdgcn_readfirstlane(n_leaf); n_piv = __builtin_amdgcn_readfirstlane(n_piv);
+    const int n_steps = n_leaf + (n_piv + WAVE - 1) / WAVE;
+    int out = 0;
+    // S_FLIGHT steps are fetched together (every fetch unconditional, the step clamped to a valid one: a load inside a
+    // branch is waited for at the branch's end): one memory round trip per S_FLIGHT x 64 photons
+    for (int s0 = 0; s0 < n_steps; s0 += S_FLIGHT) {
+        float4 p[S_FLIGHT];
+        int at[S_FLIGHT], n[S_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < S_FLIGHT; u++) {
+            at[u] = list_step(g_S.w.leaf_sorted, g_S.w.piv_sorted, s0 + u < n_steps ? s0 + u : n_steps - 1, n_leaf, n_piv, lane, n[u]);
+            if (s0 + u >= n_steps) n[u] = 0;
+            p[u] = load_global4(pos + at[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < S_FLIGHT; u++) {
+            const float dx = cx - p[u].x, dy = cy - p[u].y, dz = cz - p[u].z;      // the operation order of every other distance here
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const bool keep = lane < n[u] && d2 <= reach2;
+            const unsigned long long m = __ballot(keep);
+            const int c = __builtin_popcountll(m);
+            if (out + c > S_PACK_CAP) return -1;
+            if (keep) pack[out + (int)prefix_rank(m)] = float4{p[u].x, p[u].y, p[u].z, __uint_as_float((uint32_t)at[u])};
+            out += c;
+            const bool in = lane < n[u] && d2 < lim;
+            if (in) atomicAdd(&hist[centre_bin(d2, hscale)], 1u);
+            count += __builtin_popcountll(__ballot(in));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    *inside = count;
+    return out;
+}
+
+// The k-th smallest squared distance (k <= the count pack_listed returned) from the histogram it left: the bin that holds
+// it, then that bin's entries ranked.  Returns the bit pattern, or 0xFFFFFFFF when the bin holds more entries than the
+// list (many equal distances): the radix passes of centre_kth decide then.
+__device__ __attribute__((noinline)) uint32_t centre_select(const float4* pack, int n_pack, float cx, float cy, float cz, float lim, int k)
+{
+    uint32_t* const hist = centre_hist();
+    uint32_t* const list = hist + C_BINS;                     // C_BINS more words of the staging area
+    const int lane = lane_id();
+    // lane l owns bins 4l .. 4l + 3
+    const uint32_t h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+    const uint32_t sum = h0 + h1 + h2 + h3;
+    uint32_t incl = sum;
+    for (int off = 1; off < WAVE; off <<= 1) {
+        const uint32_t v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    const uint32_t excl = incl - sum;
+    const bool mine = (uint32_t)k > excl && (uint32_t)k <= incl;      // exactly one lane
+    uint32_t b = 0, bl = 0, ib = 0;
+    if (mine) {
+        const uint32_t w = (uint32_t)k - excl;
+        if (w <= h0) { b = 0; bl = excl; ib = h0; }
+        else if (w <= h0 + h1) { b = 1; bl = excl + h0; ib = h1; }
+        else if (w <= h0 + h1 + h2) { b = 2; bl = excl + h0 + h1; ib = h2; }
+        else { b = 3; bl = excl + h0 + h1 + h2; ib = h3; }
+        b += 4 * lane;
+    }
+    const int src = __builtin_ctzll(__ballot(mine));
+    const int bin = (int)__shfl(b, src);
+    const int need = k - (int)__shfl(bl, src);                // 1-based rank inside the bin
+    const int in_bin = (int)__shfl(ib, src);
+    if (in_bin > C_BINS) return 0xFFFFFFFFu;
+    __builtin_amdgcn_wave_barrier();
+    const float hscale = (float)C_BINS / lim;
+    n_pack = __builtin_amdgcn_readfirstlane(n_pack);
+    const int n_steps = (n_pack + WAVE - 1) / WAVE;
+    int m = 0;
+    for (int s0 = 0; s0 < n_steps; s0 += S_FLIGHT) {
+        float4 p[S_FLIGHT];
+        int n[S_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < S_FLIGHT; u++) {
+            p[u] = pack_step(pack, s0 + u < n_steps ? s0 + u : n_steps - 1, n_pack, lane, n[u]);
+            if (s0 + u >= n_steps) n[u] = 0;
+        }
+#pragma unroll
+        for (int u = 0; u < S_FLIGHT; u++) {
+            const float dx = cx - p[u].x, dy = cy - p[u].y, dz = cz - p[u].z;
+            const float d2 = dx * dx + dy * dy + dz * dz;
+            const bool hit = lane < n[u] && d2 < lim && centre_bin(d2, hscale) == bin;
+            const unsigned long long mh = __ballot(hit);
+            if (hit) list[m + (int)prefix_rank(mh)] = __float_as_uint(d2);
+            m += __builtin_popcountll(mh);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // m == in_bin; the need-th smallest of the list (entries may repeat: ties broken by position)
+    uint32_t found = 0;
+    bool have = false;
+    for (int i0 = 0; i0 < m; i0 += WAVE) {
+        const int i = i0 + lane;
+        const uint32_t e = list[i < m ? i : m - 1];
+        int rank = 0;
+        for (int j = 0; j < m; j++) { const uint32_t o = list[j]; rank += (o < e || (o == e && j < i)) ? 1 : 0; }
+        if (i < m && rank == need - 1) { found = e; have = true; }
+    }
+    const unsigned long long mf = __ballot(have);
+    __builtin_amdgcn_wave_barrier();
+    return mf ? (uint32_t)__shfl((int)found, __builtin_ctzll(mf)) : 0xFFFFFFFFu;
+}
+
 // ---- packing, second stage, in place: what lies inside the box [gl, gh] and within sqrt(reach2) of the centre
 struct Box6f { float lx, ly, lz, hx, hy, hz; };
 __device__ __attribute__((noinline)) int pack_refilter(float4* pack, int n_pack, float cx, float cy, float cz, float reach2, Box6f bx)
@@ -178,21 +275,66 @@ __device__ __attribute__((noinline)) int pack_refilter(float4* pack, int n_pack,
     const int lane = lane_id();
     n_pack = __builtin_amdgcn_readfirstlane(n_pack);
     const int n_steps = (n_pack + WAVE - 1) / WAVE;
-    int out = 0, n = 0, n_next = 0;
-    float4 p = n_steps > 0 ? pack_step(pack, 0, n_pack, lane, n) : float4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < n_steps; s++) {
-        const float4 p_next = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);      // (lies wholly behind what this step writes)
-        const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
-        const bool inside = !(p.x > bx.hx || p.x < bx.lx || p.y > bx.hy || p.y < bx.ly || p.z > bx.hz || p.z < bx.lz);
-        const bool keep = lane < n && inside && dx * dx + dy * dy + dz * dz <= reach2;
-        const unsigned long long m = __ballot(keep);
-        // the step's entries are all in registers before any of its outputs is written, and outputs never pass the step
+    int out = 0;
+    for (int s0 = 0; s0 < n_steps; s0 += S_FLIGHT) {
+        // a batch's entries are all in registers before any of its outputs is written, and outputs never pass the batch
+        float4 p[S_FLIGHT];
+        int n[S_FLIGHT];
+#pragma unroll
+        for (int u = 0; u < S_FLIGHT; u++) {
+            p[u] = pack_step(pack, s0 + u < n_steps ? s0 + u : n_steps - 1, n_pack, lane, n[u]);
+            if (s0 + u >= n_steps) n[u] = 0;
+        }
         __builtin_amdgcn_wave_barrier();
-        if (keep) pack[out + (int)prefix_rank(m)] = p;
-        out += __builtin_popcountll(m);
-        p = p_next; n = n_next;
+#pragma unroll
+        for (int u = 0; u < S_FLIGHT; u++) {
+            const float dx = p[u].x - cx, dy = p[u].y - cy, dz = p[u].z - cz;
+            const bool inside = !(p[u].x > bx.hx || p[u].x < bx.lx || p[u].y > bx.hy || p[u].y < bx.ly || p[u].z > bx.hz || p[u].z < bx.lz);
+            const bool keep = lane < n[u] && inside && dx * dx + dy * dy + dz * dz <= reach2;
+            const unsigned long long m = __ballot(keep);
+            if (keep) pack[out + (int)prefix_rank(m)] = p[u];
+            out += __builtin_popcountll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     return out;
+}
+
+// ---- a first guess at the centre's k-th distance from the photon density around it: the cell (subtree) of at most
+// S_CELL photons that holds the centre is a box whose photons -- points on a surface -- fill its bounding box, so their
+// number over the box's face area (its two largest extents) is the density there, and r_k ~ sqrt(k / (pi density)).
+// The guess only has to be close: what the walk then lists is counted, and a second walk corrects a bad one.
+__device__ __attribute__((noinline)) float centre_guess(PhotonMapView pm, float cx, float cy, float cz, int k)
+{
+    const int lane = lane_id();
+    int lo = 0, hi = (int)pm.n;
+    while (hi - lo > S_CELL) {
+        const int mid = lo + (hi - lo) / 2;
+        const float4 pv = pm.pos[mid];
+        const int ax = (int)pv.w;
+        const float split = ax == 0 ? pv.x : (ax == 1 ? pv.y : pv.z);
+        const float delta = (ax == 0 ? cx : (ax == 1 ? cy : cz)) - split;
+        if (delta < 0.f) hi = mid; else lo = mid + 1;
+    }
+    if (hi - lo < 16) return 0.f;
+    static_assert(S_CELL <= S_FLIGHT * WAVE, "one batch of loads covers the cell");
+    float4 p[S_FLIGHT];
+#pragma unroll
+    for (int u = 0; u < S_FLIGHT; u++) {
+        const int i = lo + u * WAVE + lane;
+        p[u] = load_global4(pm.pos + (i < hi ? i : hi - 1));      // (a repeated photon changes no bound)
+    }
+    float nx = p[0].x, ny = p[0].y, nz = p[0].z, xx = nx, xy = ny, xz = nz;
+#pragma unroll
+    for (int u = 1; u < S_FLIGHT; u++) {
+        nx = fminf(nx, p[u].x); ny = fminf(ny, p[u].y); nz = fminf(nz, p[u].z);
+        xx = fmaxf(xx, p[u].x); xy = fmaxf(xy, p[u].y); xz = fmaxf(xz, p[u].z);
+    }
+    const float ex = wave_max_f(xx) - wave_min_f(nx), ey = wave_max_f(xy) - wave_min_f(ny), ez = wave_max_f(xz) - wave_min_f(nz);
+    const float e_max = fmaxf(ex, fmaxf(ey, ez)), e_min = fminf(ex, fminf(ey, ez)), e_mid = ex + ey + ez - e_max - e_min;
+    const float area = e_max * e_mid;
+    if (!(area > 0.f)) return 0.f;
+    return sqrtf((float)k * area / (3.14159265f * (float)(hi - lo)));
 }
 
 // ---- the centre's k-th smallest squared distance among the packed photons with d2 < lim, by all lanes together:
@@ -209,15 +351,21 @@ __device__ __attribute__((noinline)) uint32_t centre_kth(const float4* pack, int
     for (int pass = 3; pass >= 0; pass--) {
         for (int b = lane; b < 256; b += WAVE) hist[b] = 0;
         __builtin_amdgcn_wave_barrier();
-        int n = 0, n_next = 0;
-        float4 p = n_steps > 0 ? pack_step(pack, 0, n_pack, lane, n) : float4{0.f, 0.f, 0.f, 0.f};
-        for (int s = 0; s < n_steps; s++) {
-            const float4 p_next = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);
-            const float dx = cx - p.x, dy = cy - p.y, dz = cz - p.z;      // the operation order of every other distance here
-            const float d2 = dx * dx + dy * dy + dz * dz;
-            const uint32_t u = __float_as_uint(d2);
-            if (lane < n && d2 < lim && (u & pmask) == prefix) atomicAdd(&hist[(u >> (8 * pass)) & 255u], 1u);
-            p = p_next; n = n_next;
+        for (int s0 = 0; s0 < n_steps; s0 += S_FLIGHT) {
+            float4 p[S_FLIGHT];
+            int n[S_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < S_FLIGHT; u++) {
+                p[u] = pack_step(pack, s0 + u < n_steps ? s0 + u : n_steps - 1, n_pack, lane, n[u]);
+                if (s0 + u >= n_steps) n[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < S_FLIGHT; u++) {
+                const float dx = cx - p[u].x, dy = cy - p[u].y, dz = cz - p[u].z;      // the operation order of every other distance here
+                const float d2 = dx * dx + dy * dy + dz * dz;
+                const uint32_t bits = __float_as_uint(d2);
+                if (lane < n[u] && d2 < lim && (bits & pmask) == prefix) atomicAdd(&hist[(bits >> (8 * pass)) & 255u], 1u);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         // lane l owns bins 4l .. 4l + 3: the bin holding the want-th entry
@@ -255,15 +403,51 @@ __device__ __attribute__((noinline)) uint32_t centre_kth(const float4* pack, int
 }
 
 // ---- the three passes over the packed list (see rt_gather_tile.hip.h for the arithmetic they share)
-__device__ __forceinline__ void s_stage_put(float* st, const float4& p, int lane, int n)
+// A pass fetches step s + 1 (or s + 2) from the packed list while it works on step s.  The registers that receive a
+// fetch must not be needed for anything else meanwhile -- a register of the destination reused as a temporary makes
+// the compiler wait for the fetch at once -- so the histogram and critical-bin passes, which have no use for an
+// entry's fourth word, fetch three words only.
+struct P3 { float x, y, z; };
+typedef float v3f __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ P3 pack_step_xyz(const float4* pack, int s, int n_pack, int lane, int& n)
+{
+    const int first = s * WAVE;
+    n = n_pack - first < WAVE ? n_pack - first : WAVE;
+    const v3f v = *(const v3f __attribute__((address_space(1)))*)(pack + first + (lane < n ? lane : n - 1));
+    return P3{v.x, v.y, v.z};
+}
+__device__ __forceinline__ void s_stage_put(float* st, float x, float y, float z, int lane, int n)
 {
     __builtin_amdgcn_wave_barrier();       // (the reads of the step before are done: LDS operations of a wave complete in order)
-    st[lane] = lane < n ? p.x : 1.0e18f; st[WAVE + lane] = p.y; st[2 * WAVE + lane] = p.z;
+    st[lane] = lane < n ? x : 1.0e18f; st[WAVE + lane] = y; st[2 * WAVE + lane] = z;      // (a filler no ball reaches: the loops over a step need no bound checks)
     __builtin_amdgcn_wave_barrier();
 }
 __device__ __forceinline__ Xyz4 s_quad_load(const float* st, int j)
 {
     return Xyz4{*reinterpret_cast<const float4*>(st + j), *reinterpret_cast<const float4*>(st + WAVE + j), *reinterpret_cast<const float4*>(st + 2 * WAVE + j)};
+}
+// f(what load(j) returned) for the quads j of a staged step, the next quad's data read from LDS before the current one is
+// worked on.  A full step -- all but a list's last -- is straight-line code: no wait for LDS at a loop edge.
+template <class L, class F>
+__device__ __forceinline__ void for_quads(int n_now, L&& load, F&& f)
+{
+    auto cur = load(0);
+    if (n_now == WAVE) {
+#pragma unroll
+        for (int j = 0; j < WAVE; j += 4) {
+            const auto nxt = load((j + 4) & (WAVE - 1));
+            __builtin_amdgcn_sched_barrier(0);      // (the reads stay ahead of the arithmetic: left to itself the scheduler sinks them to their first use)
+            f(cur);
+            cur = nxt;
+        }
+    } else {
+        for (int j = 0; j < n_now; j += 4) {
+            const auto nxt = load((j + 4) & (WAVE - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            f(cur);
+            cur = nxt;
+        }
+    }
 }
 
 template <bool any_radius>
@@ -279,13 +463,18 @@ __device__ __attribute__((noinline)) void stream_hist(const float4* pack, int n_
     const int n_steps = (n_pack + WAVE - 1) / WAVE;
     uint32_t* const mine = hist_mine(cell, lane);
     const uint32_t unit = hist_unit(lane);
-    int n = 0, n_next = 0;
-    float4 p = n_steps > 0 ? pack_step(pack, 0, n_pack, lane, n) : float4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < n_steps; s++, n = n_next) {
-        s_stage_put(st, p, lane, n);
+    // (the entries of steps s + 1 .. s + 3 are on their way while step s is binned: the packed lists of all waves together
+    // are larger than the caches, and a fetch from memory takes longer than a step)
+    if (n_steps == 0) return;
+    int n = 0, n1 = 0, n2 = 0, n3 = 0;
+    P3 p = pack_step_xyz(pack, 0, n_pack, lane, n);
+    P3 p1 = pack_step_xyz(pack, 1 < n_steps ? 1 : n_steps - 1, n_pack, lane, n1);
+    P3 p2 = pack_step_xyz(pack, 2 < n_steps ? 2 : n_steps - 1, n_pack, lane, n2);
+    for (int s = 0; s < n_steps; s++) {
+        s_stage_put(st, p.x, p.y, p.z, lane, n);
         const int n_now = __builtin_amdgcn_readfirstlane(n);
-        p = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);      // on its way while this step is binned
-        auto bin4 = [&](const Xyz4& c) {
+        const P3 p3 = pack_step_xyz(pack, s + 3 < n_steps ? s + 3 : n_steps - 1, n_pack, lane, n3);
+        for_quads(n_now, [&](int j) { return s_quad_load(st, j); }, [&](const Xyz4& c) {
             const D2x4 d = quad_d2(c, qx, qy, qz);
             const f2 at_a = shell_pos(d.a, sh), at_b = shell_pos(d.b, sh);
             int b0 = shell_bin_of(at_a.x), b1 = shell_bin_of(at_a.y), b2 = shell_bin_of(at_b.x), b3 = shell_bin_of(at_b.y);
@@ -297,14 +486,8 @@ __device__ __attribute__((noinline)) void stream_hist(const float4* pack, int n_
             hist_add(mine, unit, b1);
             hist_add(mine, unit, b2);
             hist_add(mine, unit, b3);
-        };
-        Xyz4 c0 = s_quad_load(st, 0), c1;
-        for (int j0 = 0; j0 < n_now; j0 += 8) {
-            c1 = s_quad_load(st, j0 + 4);
-            bin4(c0);
-            c0 = s_quad_load(st, (j0 + 8) & (WAVE - 1));
-            if (j0 + 4 < n_now) bin4(c1);
-        }
+        });
+        p = p1; n = n1; p1 = p2; n1 = n2; p2 = p3; n2 = n3;
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -322,13 +505,16 @@ __device__ __attribute__((noinline)) int stream_crit(const float4* pack, int n_p
     const float crit_f = crit >= 1 ? (float)crit : 1.0e30f;
     const f2 crit_2 = {crit_f, crit_f};
     constexpr uint32_t ONE = 0x3F800000u;
-    int n = 0, n_next = 0;
-    float4 p = n_steps > 0 ? pack_step(pack, 0, n_pack, lane, n) : float4{0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < n_steps; s++, n = n_next) {
-        s_stage_put(st, p, lane, n);
+    if (n_steps == 0) return 0;
+    int n = 0, n1 = 0, n2 = 0, n3 = 0;
+    P3 p = pack_step_xyz(pack, 0, n_pack, lane, n);
+    P3 p1 = pack_step_xyz(pack, 1 < n_steps ? 1 : n_steps - 1, n_pack, lane, n1);
+    P3 p2 = pack_step_xyz(pack, 2 < n_steps ? 2 : n_steps - 1, n_pack, lane, n2);
+    for (int s = 0; s < n_steps; s++) {
+        s_stage_put(st, p.x, p.y, p.z, lane, n);
         const int n_now = __builtin_amdgcn_readfirstlane(n);
-        p = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);
-        auto pick4 = [&](const Xyz4& c) {
+        const P3 p3 = pack_step_xyz(pack, s + 3 < n_steps ? s + 3 : n_steps - 1, n_pack, lane, n3);
+        for_quads(n_now, [&](int j) { return s_quad_load(st, j); }, [&](const Xyz4& c) {
             const D2x4 d = quad_d2(c, qx, qy, qz);
             const f2 at_a = shell_pos(d.a, sh), at_b = shell_pos(d.b, sh);
             const f2 t_a = at_a - crit_2, t_b = at_b - crit_2;
@@ -343,20 +529,21 @@ __device__ __attribute__((noinline)) int stream_crit(const float4* pack, int n_p
                 if (u2 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.x); cnt++; }
                 if (u3 < ONE && cnt < T_CRIT) { cell[cnt * WAVE + lane] = __float_as_uint(d.b.y); cnt++; }
             }
-        };
-        Xyz4 c0 = s_quad_load(st, 0), c1;
-        for (int j0 = 0; j0 < n_now; j0 += 8) {
-            c1 = s_quad_load(st, j0 + 4);
-            pick4(c0);
-            c0 = s_quad_load(st, (j0 + 8) & (WAVE - 1));
-            if (j0 + 4 < n_now) pick4(c1);
-        }
+        });
+        p = p1; n = n1; p1 = p2; n1 = n2; p2 = p3; n2 = n3;
     }
     __builtin_amdgcn_wave_barrier();
     return cnt;
 }
 
-// the sums of main.cpp:262-291 over the photons with d2 <= t_k (see pass_sum)
+// the sums of main.cpp:262-291 over the photons with d2 <= t_k (see pass_sum).  Power and direction of a photon are
+// fetched by the tree position its entry carries, so the entries run two steps ahead of the arithmetic and the records one.
+struct Aux6 { float b0, b1, b2, b3, b4, b5; };
+__device__ __forceinline__ Aux6 aux_fetch(const float* aux, uint32_t at)
+{
+    const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)at;
+    return Aux6{ax[0], ax[1], ax[2], ax[3], ax[4], ax[5]};
+}
 __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_pack, const float* __restrict__ aux, float qx, float qy, float qz, float t_k, bool some,
                                                      float nx, float ny, float nz)
 {
@@ -367,39 +554,36 @@ __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_p
     double s0 = 0, s1 = 0, s2 = 0;
     n_pack = __builtin_amdgcn_readfirstlane(n_pack);
     const int n_steps = (n_pack + WAVE - 1) / WAVE;
+    if (n_steps == 0) return Sum3{0, 0, 0};
     const float lim = some ? t_k : -1.f;
-    int n = 0, n_next = 0;
-    float4 p = float4{0.f, 0.f, 0.f, 0.f};
-    float b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0;
-    if (n_steps > 0) {
-        p = pack_step(pack, 0, n_pack, lane, n);
-        const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)__float_as_uint(p.w);
-        b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
-    }
-    for (int s = 0; s < n_steps; s++, n = n_next) {
-        s_stage_put(st, p, lane, n);
+    int n = 0, n1 = 0, n2 = 0;
+    float4 p = pack_step(pack, 0, n_pack, lane, n);                                    // step s
+    float4 p1 = pack_step(pack, n_steps > 1 ? 1 : 0, n_pack, lane, n1);               // step s + 1
+    Aux6 a = aux_fetch(aux, __float_as_uint(p.w));                                     // records of step s
+    for (int s = 0; s < n_steps; s++) {
+        s_stage_put(st, p.x, p.y, p.z, lane, n);
         {
-            sa[lane] = b0; sa[WAVE + lane] = b1; sa[2 * WAVE + lane] = b2; sa[3 * WAVE + lane] = b3; sa[4 * WAVE + lane] = b4; sa[5 * WAVE + lane] = b5;
+            sa[lane] = a.b0; sa[WAVE + lane] = a.b1; sa[2 * WAVE + lane] = a.b2; sa[3 * WAVE + lane] = a.b3; sa[4 * WAVE + lane] = a.b4; sa[5 * WAVE + lane] = a.b5;
             __builtin_amdgcn_wave_barrier();
         }
         const int n_now = __builtin_amdgcn_readfirstlane(n);
-        {      // the next step's photons, power and direction are on their way while this step's are used
-            p = pack_step(pack, s + 1 < n_steps ? s + 1 : s, n_pack, lane, n_next);
-            const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)__float_as_uint(p.w);
-            b0 = ax[0]; b1 = ax[1]; b2 = ax[2]; b3 = ax[3]; b4 = ax[4]; b5 = ax[5];
-        }
-        struct Aux4 { float4 pr, pg, pb, ux, uy, uz; };
-        auto aux_load = [&](int j) {
-            return Aux4{*reinterpret_cast<const float4*>(sa + j), *reinterpret_cast<const float4*>(sa + WAVE + j), *reinterpret_cast<const float4*>(sa + 2 * WAVE + j),
+        // on their way while this step is summed (unconditional, clamped to the last step: a fetch inside a branch is waited for
+        // at the branch's end): the records of step s + 1, whose entries arrived a step ago, and the entries of step s + 2
+        a = aux_fetch(aux, __float_as_uint(p1.w));
+        const float4 p2 = pack_step(pack, s + 2 < n_steps ? s + 2 : n_steps - 1, n_pack, lane, n2);
+        struct Quad { Xyz4 c; float4 pr, pg, pb, ux, uy, uz; };
+        auto quad_all = [&](int j) {
+            return Quad{s_quad_load(st, j), *reinterpret_cast<const float4*>(sa + j), *reinterpret_cast<const float4*>(sa + WAVE + j), *reinterpret_cast<const float4*>(sa + 2 * WAVE + j),
                         *reinterpret_cast<const float4*>(sa + 3 * WAVE + j), *reinterpret_cast<const float4*>(sa + 4 * WAVE + j), *reinterpret_cast<const float4*>(sa + 5 * WAVE + j)};
         };
-        auto sum4 = [&](const Xyz4& c, const Aux4& a) {
-            const D2x4 d = quad_d2(c, qx, qy, qz);
-            const float4 &pr4 = a.pr, &pg4 = a.pg, &pb4 = a.pb, &ux4 = a.ux, &uy4 = a.uy, &uz4 = a.uz;
-            // four photons at a time without a branch per photon: one outside the lane's ball contributes a factor 0;
-            // the four terms of a channel are added in float before they join the double sum
+        for_quads(n_now, quad_all, [&](const Quad& q) {
+            const D2x4 d = quad_d2(q.c, qx, qy, qz);
+            // four photons at a time without a branch per photon or per quad: one outside the lane's ball contributes a
+            // factor 0 (the packed list holds little that lies outside every ball); the four terms of a channel are added in
+            // float before they join the double sum
             const bool in0 = d.a.x <= lim, in1 = d.a.y <= lim, in2 = d.b.x <= lim, in3 = d.b.y <= lim;
-            if (__ballot(in0 || in1 || in2 || in3)) {
+            {
+                const float4 &pr4 = q.pr, &pg4 = q.pg, &pb4 = q.pb, &ux4 = q.ux, &uy4 = q.uy, &uz4 = q.uz;
                 const f2 c2 = {tc.c2, tc.c2}, A = {tc.A, tc.A}, B = {tc.B, tc.B};
                 const f2 ea = c2 * d.a, eb = c2 * d.b;
                 const f2 wa = A + B * f2{__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)}, wb = A + B * f2{__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)};
@@ -414,15 +598,9 @@ __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_p
                 s1 += (double)(g.x + g.y);
                 s2 += (double)(b.x + b.y);
             }
-        };
-        Xyz4 c0 = s_quad_load(st, 0), c1;
-        Aux4 a0 = aux_load(0), a1;
-        for (int j0 = 0; j0 < n_now; j0 += 8) {
-            c1 = s_quad_load(st, j0 + 4); a1 = aux_load(j0 + 4);
-            sum4(c0, a0);
-            c0 = s_quad_load(st, (j0 + 8) & (WAVE - 1)); a0 = aux_load((j0 + 8) & (WAVE - 1));
-            if (j0 + 4 < n_now) sum4(c1, a1);
-        }
+        });
+        p = p1; n = n1;
+        p1 = p2; n1 = n2;
     }
     return Sum3{s0, s1, s2};
 }
@@ -430,8 +608,10 @@ __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_p
 // Slots of the cycle accounting that mean something else here than in gather_tile_kernel: TP_KTH = walk + packing + the
 // centre's radix passes of all attempts, TP_WALK = the in-place filter, TP_N_HIST = attempts, TP_N_CRIT = photons packed
 // by the last attempt, TP_N_SUM = photons streamed by the passes.
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void gather_stream_kernel(PhotonMapView pm, TileArgs ta, GatherParams gp, double* __restrict__ acc,
-                                                                                                         float4* pack_all)
+// PROF: the instantiation with the cycle accounting (its counters take some ninety registers), launched only when
+// TileArgs::prof is given.
+template <bool PROF>
+__device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, const TileArgs& ta, const GatherParams& gp, double* __restrict__ acc, float4* pack_all)
 {
     uint32_t* const cell = g_S.table;
     const int lane = lane_id();
@@ -439,12 +619,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     const rtq::Map map = rtq::map_units(ta.cnt, ta.shard_cap, WAVE);
     const uint32_t n_windows = map.total;
     if (lane == 0) atomicAdd(ta.windows_done + 1, 1ull);
-    unsigned long long pr[TP_SLOTS] = {};
-    const unsigned long long t_begin = ta.prof ? clock64() : 0ull;
+    unsigned long long pr[TP_SLOTS] = {};      // (dead, and gone, in the instantiation without the accounting)
+    const unsigned long long t_begin = PROF ? clock64() : 0ull;
     const float r_max = sqrtf(gp.r2);
     float prev_r = -1.f;                 // the last centre's k-th distance: the next guess
-#define TILE_PROF(slot, expr) do { if (ta.prof) { const unsigned long long t_ = clock64(); expr; pr[slot] += clock64() - t_; } else { expr; } } while (0)
-#define TILE_COUNT(slot, cond) do { if (ta.prof) pr[slot] += __builtin_popcountll(__ballot(cond)); } while (0)
+#define TILE_PROF(slot, expr) do { if (PROF) { const unsigned long long t_ = clock64(); expr; pr[slot] += clock64() - t_; } else { expr; } } while (0)
+#define TILE_COUNT(slot, cond) do { if (PROF) pr[slot] += __builtin_popcountll(__ballot(cond)); } while (0)
     while (true) {
         unsigned long long w0 = 0;
         if (lane == 0) w0 = atomicAdd(ta.next, 1ull);
@@ -465,8 +645,10 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         const bool sss = (flags & GATHER_SSS) != 0;
         bool redo = have && ((flags & ~(GATHER_SSS | GATHER_MARCH)) != 0 || (sss && !ta.sss_surface) || ta.all_redo || pm.n >= (1ll << 24));
         bool todo = have && !redo;
-        pr[TP_WINDOWS]++;
+        if (PROF) pr[TP_WINDOWS]++;
         TILE_COUNT(TP_R_FLAGS, redo);
+        const unsigned long long t_window = PROF ? clock64() : 0ull;
+        int rounds_done = 0;
         // A window mostly holds one patch of neighbouring hit points, but it may hold a few (a tile across a silhouette):
         // each round takes the requests close to one of those still waiting; what is left after the last round, and
         // rounds of only a few requests, go to the per-request kernel.
@@ -500,11 +682,15 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             int n_pack = 0;
             bool found = false;
             {
-                const unsigned long long t_kth = ta.prof ? clock64() : 0ull;
-                float guess = prev_r > 0.f ? prev_r * 1.2f : r_max * 0.3f;
-                float too_small = 0.f, too_large = 3.0e38f;      // guesses that held fewer than k photons / overflowed the lists
+                const unsigned long long t_kth = PROF ? clock64() : 0ull;
+                // The guess only has to be within a factor of a few: the photons actually counted inside it correct it
+                // (density ~ count / R^2 on a surface), so a second walk, where one is needed, starts from a good radius.
+                float guess;
+                TILE_PROF(TP_C_GUESS, guess = centre_guess(pm, cx, cy, cz, gp.k) * 1.15f);
+                if (!(guess > 0.f)) { guess = prev_r > 0.f ? prev_r * 1.2f : r_max * 0.3f; if (PROF) pr[TP_A_NOGUESS]++; }
+                float too_small = 0.f, too_large = 3.0e38f;      // radii that held fewer than k photons / overflowed the lists
                 for (int attempt = 0; attempt < S_ATTEMPTS && !found; attempt++) {
-                    pr[TP_N_HIST]++;
+                    if (PROF) pr[TP_N_HIST]++;
                     const float R = fminf(guess, r_max);
                     const bool whole = !(R < r_max);                            // the search radius itself: nothing larger to try
                     const bool cand = near && d_c <= R;                         // who can be in the round if r_c <= R
@@ -515,35 +701,54 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
                     const float ghx = wave_max_f(cand ? qx + rad : -big), ghy = wave_max_f(cand ? qy + rad : -big), ghz = wave_max_f(cand ? qz + rad : -big);
                     const float reach = wave_max_f(cand ? d_c : 0.f) + rad;
                     __builtin_amdgcn_wave_barrier();
-                    const int lists = stream_walk(pm, glx, gly, glz, ghx, ghy, ghz);
-                    int packed = -1;
-                    if (lists >= 0) {
-                        const int n_leaf = lists & 0xFFFF, n_piv = lists >> 16;
-                        rank_sort(g_S.w.leaf, g_S.w.leaf_sorted, n_leaf);
-                        rank_sort(g_S.w.piv, g_S.w.piv_sorted, n_piv);
-                        __builtin_amdgcn_wave_barrier();
-                        packed = pack_listed(pm.pos, pack, cx, cy, cz, reach * reach * 1.0001f, n_leaf, n_piv);
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    if (packed < 0) {
+                    int lists;
+                    TILE_PROF(TP_C_WALK, lists = stream_walk(pm, glx, gly, glz, ghx, ghy, ghz));
+                    if (lists < 0) {
+                        if (PROF) pr[TP_A_LISTS]++;
                         // too much of the tree: a smaller radius, unless that is known to hold fewer than k photons
-                        too_large = R;
+                        too_large = fminf(too_large, R);
                         guess = fmaxf(R * 0.6f, sqrtf(too_small * R));
                         if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
                         continue;
                     }
-                    int total = 0;
-                    const uint32_t bits = centre_kth(pack, packed, cx, cy, cz, whole ? gp.r2 : R * R, gp.k, &total);
+                    const int n_leaf = lists & 0xFFFF, n_piv = lists >> 16;
+                    TILE_PROF(TP_C_SORT, rank_sort(g_S.w.leaf, g_S.w.leaf_sorted, n_leaf); rank_sort(g_S.w.piv, g_S.w.piv_sorted, n_piv));
                     __builtin_amdgcn_wave_barrier();
-                    if (total >= gp.k) { r_c = sqrtf(__uint_as_float(bits)); n_pack = packed; found = true; }
-                    else if (whole) { r_c = -1.f; n_pack = packed; found = true; }      // fewer than k within the search radius
-                    else {
-                        too_small = R;
-                        guess = fminf(R * 1.4f, too_large < 3.0e38f ? sqrtf(R * too_large) : 3.0e38f);
-                        if (guess >= too_large * 0.98f || guess <= R * 1.02f) break;
+                    const float lim = whole ? gp.r2 : R * R;
+                    int packed, inside = 0;
+                    TILE_PROF(TP_C_PACK, packed = pack_listed(pm.pos, pack, cx, cy, cz, reach * reach * 1.0001f, lim, n_leaf, n_piv, &inside));
+                    __builtin_amdgcn_wave_barrier();
+                    if (packed < 0) {
+                        if (PROF) pr[TP_A_PACK]++;
+                        too_large = fminf(too_large, R);
+                        guess = fmaxf(R * 0.7f, sqrtf(too_small * R));
+                        if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
+                        continue;
                     }
+                    if (inside < gp.k && !whole) {
+                        // too few: the radius that would hold k at the density just counted, and a margin
+                        if (PROF) pr[TP_A_FEW]++;
+                        too_small = fmaxf(too_small, R);
+                        const float grow = sqrtf((float)gp.k / (float)(inside > 0 ? inside : 1)) * 1.15f;
+                        guess = fminf(R * fminf(grow, 3.f), too_large < 3.0e38f ? sqrtf(R * too_large) : 3.0e38f);
+                        if (guess >= too_large * 0.98f || guess <= R * 1.02f) break;
+                        continue;
+                    }
+                    if (PROF && inside > 2 * gp.k) pr[TP_A_MANY]++;      // (more than needed: the filter below cuts the list down)
+                    uint32_t bits = 0;
+                    if (inside >= gp.k) {
+                        TILE_PROF(TP_C_KTH, bits = centre_select(pack, packed, cx, cy, cz, lim, gp.k));
+                        if (bits == 0xFFFFFFFFu) {
+                            int total = 0;
+                            bits = centre_kth(pack, packed, cx, cy, cz, lim, gp.k, &total);
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    n_pack = packed;
+                    found = true;
+                    r_c = inside >= gp.k ? sqrtf(__uint_as_float(bits)) : -1.f;      // (fewer than k: only within the search radius itself)
                 }
-                if (ta.prof) pr[TP_KTH] += clock64() - t_kth;
+                if (PROF) pr[TP_KTH] += clock64() - t_kth;
             }
             if (!found) {      // the lists cannot hold what the centre's ball touches
                 TILE_COUNT(TP_R_WALK, near);
@@ -588,12 +793,13 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
                 bx.lx = wave_min_f(act ? qx - rad : big); bx.ly = wave_min_f(act ? qy - rad : big); bx.lz = wave_min_f(act ? qz - rad : big);
                 bx.hx = wave_max_f(act ? qx + rad : -big); bx.hy = wave_max_f(act ? qy + rad : -big); bx.hz = wave_max_f(act ? qz + rad : -big);
                 const float reach = wave_max_f(act ? d_c + rad : 0.f);
-                pr[TP_N_CRIT] += n_pack;
+                if (PROF) pr[TP_N_CRIT] += n_pack;
                 TILE_PROF(TP_WALK, n_pack = pack_refilter(pack, n_pack, cx, cy, cz, reach * reach * 1.0001f, bx));
                 __builtin_amdgcn_wave_barrier();
             }
             const int n_steps = (n_pack + WAVE - 1) / WAVE;
-            pr[TP_ROUNDS]++; pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_steps; pr[TP_N_SUM] += n_pack;
+            rounds_done++;
+            if (PROF) pr[TP_ROUNDS]++; if (PROF) pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_steps; if (PROF) pr[TP_N_SUM] += n_pack;
 
             const Shell sh = shell_of(bound, lower);
             const float radius2 = act && !(bound < gp.r2) ? gp.r2 : 3.0e38f;      // lanes bounded by the search radius itself
@@ -632,7 +838,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             int cnt;
             if (any_radius) TILE_PROF(TP_CRIT, cnt = stream_crit<true>(pack, n_pack, qx, qy, qz, sh, radius2, some ? crit : -1));
             else TILE_PROF(TP_CRIT, cnt = stream_crit<false>(pack, n_pack, qx, qy, qz, sh, radius2, some ? crit : -1));
-            const unsigned long long t_rank = ta.prof ? clock64() : 0ull;
+            const unsigned long long t_rank = PROF ? clock64() : 0ull;
             const int max_cnt = (int)wave_max_f((float)cnt);
             uint32_t t_bits = 0;
             for (int i0 = 0; i0 < max_cnt; i0 += 8) {
@@ -667,7 +873,7 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
             if (split_tie) redo = true;
             const bool summed = some && !split_tie;
             __builtin_amdgcn_wave_barrier();
-            if (ta.prof) pr[TP_RANK] += clock64() - t_rank;
+            if (PROF) pr[TP_RANK] += clock64() - t_rank;
             // ---- 3c. the estimate over the set (main.cpp:262-295)
             Sum3 sum;
             TILE_PROF(TP_SUM, sum = stream_sum(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2]));
@@ -688,6 +894,14 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
         }
         TILE_COUNT(TP_R_LEFT, todo);
         redo = redo || todo;
+        if (PROF) {
+            const unsigned long long dt = clock64() - t_window;
+            if (rounds_done <= 1) { pr[TP_W_ROUNDS1]++; pr[TP_W_CYC1] += dt; }
+            else if (rounds_done == 2) { pr[TP_W_ROUNDS2]++; pr[TP_W_CYC2] += dt; }
+            else if (rounds_done == 3) { pr[TP_W_ROUNDS3]++; pr[TP_W_CYC3] += dt; }
+            else { pr[TP_W_ROUNDS4]++; pr[TP_W_CYC4] += dt; }
+            if (dt > pr[TP_W_MAX]) pr[TP_W_MAX] = dt;
+        }
         // ---- requests left to the per-request kernel
         const unsigned long long m_redo = __ballot(redo);
         if (m_redo) {
@@ -703,11 +917,28 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) vo
     }
 #undef TILE_PROF
 #undef TILE_COUNT
-    if (ta.prof && lane == 0) {
+    if (PROF && lane == 0) {
         pr[TP_BUSY] = clock64() - t_begin;
-        for (int i = 0; i < TP_BUSY_MAX; i++) atomicAdd(&ta.prof[i], pr[i]);
+#pragma unroll
+        for (int i = 0; i < TP_BUSY_MAX; i++)
+            if (i != TP_W_MAX && i != TP_W_FIRST_MIN && i != TP_W_LAST_MAX) atomicAdd(&ta.prof[i], pr[i]);
         atomicMax(&ta.prof[TP_BUSY_MAX], pr[TP_BUSY]);
+        atomicMax(&ta.prof[TP_W_MAX], pr[TP_W_MAX]);
+        atomicMax(&ta.prof[TP_W_LAST_MAX], (unsigned long long)clock64());                   // when the last wave ended
+        atomicMin(&ta.prof[TP_W_FIRST_MIN], t_begin);                                        // when the first wave began (the slot starts at all ones)
     }
+}
+
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void gather_stream_kernel(PhotonMapView pm, TileArgs ta, GatherParams gp, double* __restrict__ acc,
+                                                                                                         float4* pack_all)
+{
+    gather_stream_body<false>(pm, ta, gp, acc, pack_all);
+}
+// (the accounting's registers would spill at three waves per SIMD and distort what it measures)
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_stream_prof_kernel(PhotonMapView pm, TileArgs ta, GatherParams gp, double* __restrict__ acc,
+                                                                                                              float4* pack_all)
+{
+    gather_stream_body<true>(pm, ta, gp, acc, pack_all);
 }
 
 }  // namespace rtg

@@ -82,7 +82,11 @@ struct TileArgs {
     unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
 };
 enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_N_HIST, TP_N_CRIT, TP_N_SUM,
-                TP_R_FLAGS, TP_R_FEW, TP_R_WALK, TP_R_SHORT, TP_R_CROWD, TP_R_LEFT, TP_R_TIE, TP_BUSY, TP_BUSY_MAX, TP_SLOTS };      // TP_R_*: requests handed on, by reason
+                TP_R_FLAGS, TP_R_FEW, TP_R_WALK, TP_R_SHORT, TP_R_CROWD, TP_R_LEFT, TP_R_TIE,      // TP_R_*: requests handed on, by reason
+                // the packed form's search for the centre's radius: cycles by part, and attempts by outcome
+                TP_C_GUESS, TP_C_WALK, TP_C_COUNT, TP_C_SORT, TP_C_PACK, TP_C_KTH, TP_A_NOGUESS, TP_A_LISTS, TP_A_FEW, TP_A_MANY, TP_A_PACK,
+                TP_W_ROUNDS1, TP_W_ROUNDS2, TP_W_ROUNDS3, TP_W_ROUNDS4, TP_W_CYC1, TP_W_CYC2, TP_W_CYC3, TP_W_CYC4, TP_W_MAX, TP_W_FIRST_MIN, TP_W_LAST_MAX,      // windows by rounds taken: count, cycles; longest window
+                TP_BUSY, TP_BUSY_MAX, TP_SLOTS };
 
 typedef float f2 __attribute__((ext_vector_type(2)));   // two photons per packed instruction
 
@@ -227,8 +231,8 @@ __device__ __forceinline__ D2x4 quad_d2(const Xyz4& c, float qx, float qy, float
 // Histogram bin of a squared distance: bin 0 holds everything below `lower` (distances the triangle inequality
 // already puts inside the set), bins 1 .. T_BINS - 2 are linear over [lower, bound), the last bin takes everything
 // from `bound` on (and the filler photons of a short step), so no photon needs a comparison with the bound.
-// The position d2 * scale + offset is monotone in d2 as evaluated (a product with a positive factor, then a sum), which
-// is all the selection needs; rounding moves a bin's edge by a few units in the last place of the position.
+// The position d2 * scale + offset is monotone in d2 as evaluated (one fused multiply-add with a positive factor: a single
+// rounding of a monotone function), which is all the selection needs; every pass forms it with this one function.
 struct Shell { float scale, offset; };
 __device__ __forceinline__ Shell shell_of(float bound, float lower)
 {
@@ -237,7 +241,7 @@ __device__ __forceinline__ Shell shell_of(float bound, float lower)
     sh.offset = 1.f - lower * sh.scale;
     return sh;
 }
-__device__ __forceinline__ f2 shell_pos(f2 d2, const Shell& sh) { return d2 * f2{sh.scale, sh.scale} + f2{sh.offset, sh.offset}; }
+__device__ __forceinline__ f2 shell_pos(f2 d2, const Shell& sh) { return __builtin_elementwise_fma(d2, f2{sh.scale, sh.scale}, f2{sh.offset, sh.offset}); }
 __device__ __forceinline__ int shell_bin_of(float pos) { return (int)__builtin_amdgcn_fmed3f(pos, 0.f, (float)(T_BINS - 1)); }
 // The histograms: lanes l and l + 32 share the word bin * 32 + l, the lower lane counting in its low half.  (A
 // wave's LDS operation goes through in two halves of 32 lanes, so the two never meet in one pass.)
