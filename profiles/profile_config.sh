@@ -27,5 +27,6 @@ TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE
 FETCH_SIZE
 WRITE_SIZE
 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
+SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_SCA SQ_INSTS_WAVE32_LDS
 PASSES
 echo "profile of $CFG done: $OUT"

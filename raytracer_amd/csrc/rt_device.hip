@@ -105,15 +105,19 @@ int upload_n(DevBuf& b, const T* v, size_t n, hipStream_t s)
 // ---- working memory of the entry point that allocates nothing (rt_knn_estimate_dev_noalloc) -----------------------
 // One fixed array per GPU the library runs on, held until the process ends: [counter block + overflow latch]
 // [request queue: RT_NOALLOC_MAX_REQUESTS records] [list of the requests the group kernel hands on] [packed photon
-// lists of NA_PACK_WAVES waves].
+// lists of NA_PACK_WAVES waves] [window parts the group kernel's waves hand to each other].
 constexpr size_t NA_COUNTERS = rtk::LATCH_OFFSET + 256;
 constexpr size_t NA_QUEUE = (size_t)RT_NOALLOC_MAX_REQUESTS * sizeof(rtg::GatherRec);
 constexpr size_t NA_REDO = (size_t)RT_NOALLOC_MAX_REQUESTS * sizeof(uint32_t);
 constexpr int NA_PACK_WAVES = 512;      // waves of the group kernel this entry point launches: each needs a packed photon list
-constexpr size_t NA_PACK = (size_t)NA_PACK_WAVES * rtg::S_PACK_CAP * sizeof(float4);
+constexpr int NA_PACK_CAP = 4096;       // photons per packed list here (the entry points that allocate use rtg::S_PACK_CAP)
+constexpr size_t NA_PACK = (size_t)NA_PACK_WAVES * NA_PACK_CAP * sizeof(float4);
+constexpr unsigned NA_CONT_ENTRIES = RT_NOALLOC_MAX_REQUESTS / 64;      // window parts handed from wave to wave, per list: one per window (beyond that, rounds stay with their wave)
+constexpr size_t NA_CONT = rtg::CONT_SHARDS * (4 + 2 * (size_t)NA_CONT_ENTRIES) * sizeof(unsigned long long);
 static_assert(RT_NOALLOC_MAX_REQUESTS % 64 == 0 && NA_QUEUE % 256 == 0, "the queue is whole windows and the list behind it stays aligned");
 static_assert(NA_REDO % 256 == 0, "the packed lists behind the hand-over list stay aligned");
-static __device__ __align__(256) unsigned char scratch[NA_COUNTERS + NA_QUEUE + NA_REDO + NA_PACK];
+static_assert(NA_PACK % 256 == 0, "the list of handed-on parts behind the packed lists stays aligned");
+static __device__ __align__(256) unsigned char scratch[NA_COUNTERS + NA_QUEUE + NA_REDO + NA_PACK + NA_CONT];
 // `scratch` is a host-side stand-in here, not a device address: host code uses the address hipGetSymbolAddress
 // gave for it on the device in question (every GPU holds its own copy of the array at its own address).
 constexpr int NA_MAX_DEVICES = 64;
@@ -161,7 +165,8 @@ struct rt_context {
     rtg::PhotonMapView pm[2] = {};
     // render queues
     DevBuf hits_a, hits_b, rays, gq, acc, redo;
-    DevBuf pack;              // packed photon lists of the group gather's waves (rtg::S_PACK_CAP entries each)
+    DevBuf pack;              // packed photon lists of the group gather's waves
+    DevBuf cont;              // window parts the group gather's waves hand to each other (rtg::TileArgs::cont)
     // staging for the host-buffer convenience entry points
     DevBuf st_org, st_dir, st_dist, st_ids, st_aux;
 };
@@ -389,7 +394,8 @@ int rt_context_create(int device, rt_context** out)
         }
         // (the hand-over list is all "empty" between calls: set once here, kept so by the kernels that read it; the
         // memset is waited for, since the contexts' streams do not wait for the null stream)
-        if (hipMemset((unsigned char*)at + NA_COUNTERS + NA_QUEUE, 0xFF, NA_REDO) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+        if (hipMemset((unsigned char*)at + NA_COUNTERS + NA_QUEUE, 0xFF, NA_REDO) != hipSuccess ||
+            hipMemset((unsigned char*)at + NA_COUNTERS + NA_QUEUE + NA_REDO + NA_PACK, 0, NA_CONT) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
             hipEventCreateWithFlags(&g_scratch_done[device], hipEventDisableTiming) != hipSuccess) {
             (void)hipStreamDestroy(ctx->stream);
             delete ctx;
@@ -423,7 +429,7 @@ void rt_context_destroy(rt_context* ctx)
     if (ctx->side) (void)hipStreamSynchronize(ctx->side);
     for (DevBuf* b : {&ctx->nodes64, &ctx->prims64, &ctx->planes64, &ctx->nodes32, &ctx->prims32, &ctx->planes32, &ctx->objs, &ctx->obj_live, &ctx->texdesc,
                       &ctx->texels, &ctx->counters, &ctx->ctr_log, &ctx->st_org, &ctx->st_dir, &ctx->st_dist, &ctx->st_ids, &ctx->st_aux, &ctx->hits_a,
-                      &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->redo, &ctx->pack, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
+                      &ctx->hits_b, &ctx->rays, &ctx->gq, &ctx->acc, &ctx->redo, &ctx->pack, &ctx->cont, &ctx->ph_pos[0], &ctx->ph_pos[1], &ctx->ph_aux[0], &ctx->ph_aux[1], &ctx->ph_axis[0],
                       &ctx->ph_axis[1], &ctx->ph_order[0], &ctx->ph_order[1], &ctx->ph_box[0], &ctx->ph_box[1], &ctx->ph_src[0], &ctx->ph_src[1],
                       &ctx->ph_raw[0], &ctx->ph_raw[1], &ctx->kd_work})
         b->release();
@@ -1471,7 +1477,8 @@ int rt_knn_estimate(rt_context* ctx, const rt_render_params* p, int64_t n, const
 namespace {
 int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
                   unsigned long long* n_redo, unsigned long long* next_gather, unsigned long long* windows_done, const rtg::GatherParams& gp, double* d_acc,
-                  uint32_t* d_redo, size_t redo_entries, bool may_profile = true, float4* d_pack = nullptr, int pack_waves = 0);
+                  uint32_t* d_redo, size_t redo_entries, bool may_profile = true, float4* d_pack = nullptr, int pack_waves = 0, int pack_cap = 0,
+                  unsigned long long* d_cont = nullptr, unsigned cont_cap = 0);
 int reserve_redo(rt_context* ctx, size_t entries);
 }
 extern "C" {
@@ -1582,7 +1589,8 @@ int rt_knn_estimate_dev_noalloc(rt_context* ctx, const rt_render_params* p, int6
     gp.photon_num = (double)p->photon_num;
     gp.seed = 12345u;
     rc = launch_gather(ctx, recs, &ctr->gather, (unsigned long long)slots, &ctr->next_window, &ctr->n_redo, &ctr->next_gather, ctr->tile_progress, gp, d_rgb, redo,
-                       NA_REDO / sizeof(uint32_t), false, (float4*)(base + NA_COUNTERS + NA_QUEUE + NA_REDO), NA_PACK_WAVES);
+                       NA_REDO / sizeof(uint32_t), false, (float4*)(base + NA_COUNTERS + NA_QUEUE + NA_REDO), NA_PACK_WAVES, NA_PACK_CAP,
+                       (unsigned long long*)(base + NA_COUNTERS + NA_QUEUE + NA_REDO + NA_PACK), NA_CONT_ENTRIES);
     // (recorded even when a launch failed part-way: whatever did get enqueued uses the array)
     if (hipEventRecord(g_scratch_done[ctx->device], ctx->stream) == hipSuccess) g_scratch_used[ctx->device] = true;
     return rc;
@@ -1594,9 +1602,10 @@ namespace {
 
 // The gather over a queue of request windows: the group kernel, then the per-request kernel for what it
 // left.  RT_GATHER_MODE=query hands every request to the per-request kernel (comparison runs).
+constexpr unsigned CONT_ENTRIES = 1u << 15;      // window parts per list handed between the group kernel's waves at most (8 lists, 4 MB; a full list keeps rounds with their wave)
 int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts* cnt, unsigned long long shard_cap, unsigned long long* next_window,
                   unsigned long long* n_redo, unsigned long long* next_gather, unsigned long long* windows_done, const rtg::GatherParams& gp, double* d_acc,
-                  uint32_t* d_redo, size_t redo_entries, bool may_profile, float4* d_pack, int pack_waves)
+                  uint32_t* d_redo, size_t redo_entries, bool may_profile, float4* d_pack, int pack_waves, int pack_cap, unsigned long long* d_cont, unsigned cont_cap)
 {
     const char* mode = getenv("RT_GATHER_MODE");
     // RT_GATHER_FORM=tile: the earlier group kernel, which streams the listed leaves themselves (comparison runs)
@@ -1607,17 +1616,33 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     if (const char* e = getenv("RT_GATHER_WAVES")) tile_waves = ctx->num_cus * std::max(1, std::min(12, atoi(e)));      // tuning aid: waves per CU
     if (packed) {
         if (!d_pack) {
+            pack_cap = rtg::S_PACK_CAP;
+            if (const char* e = getenv("RT_GATHER_PACK_CAP")) pack_cap = std::max(1024, std::min(rtg::S_PACK_CAP, atoi(e)));      // tuning aid
             int rc_p = ctx->pack.reserve((size_t)tile_waves * rtg::S_PACK_CAP * sizeof(float4));
             if (rc_p) return rc_p;
             d_pack = (float4*)ctx->pack.p;
+            // the list of window parts handed from wave to wave: zero when fresh, left zero by the kernel that used it
+            const size_t cont_bytes = rtg::CONT_SHARDS * (4 + 2 * (size_t)CONT_ENTRIES) * sizeof(unsigned long long);
+            if (ctx->cont.bytes < cont_bytes) {
+                if ((rc_p = ctx->cont.reserve(cont_bytes))) return rc_p;
+                HIP_TRY(hipMemsetAsync(ctx->cont.p, 0, cont_bytes, ctx->stream));
+            }
+            d_cont = (unsigned long long*)ctx->cont.p;
+            cont_cap = CONT_ENTRIES;
         } else {
             tile_waves = std::min(tile_waves, pack_waves);
         }
+        if (getenv("RT_GATHER_NO_PARTS")) d_cont = nullptr;      // (the switch: comparison runs -- every round of a window stays with the wave that drew it)
+        // (the lists' counts start at zero; their entries are zero already)
+        if (d_cont) HIP_TRY(hipMemset2DAsync(d_cont, (4 + 2 * (size_t)cont_cap) * sizeof(unsigned long long), 0, 4 * sizeof(unsigned long long), rtg::CONT_SHARDS, ctx->stream));
     }
     // RT_GATHER_PROF=1: per-phase cycle totals of the group kernel, printed to stderr (development aid)
     const bool prof = may_profile && getenv("RT_GATHER_PROF") != nullptr;      // (the cycle accounting allocates its table)
     int rc;
-    if (prof && (rc = ctx->st_aux.reserve(rtg::TP_SLOTS * 8))) return rc;
+    // RT_GATHER_SPAN=1: when each wave of the packed form began and ended, condensed to stderr (development aid)
+    const bool span = may_profile && packed && !prof && getenv("RT_GATHER_SPAN") != nullptr;
+    if ((prof || span) && (rc = ctx->st_aux.reserve(std::max<size_t>(rtg::TP_SLOTS * 8, (size_t)tile_waves * 24)))) return rc;
+    if (span) HIP_TRY(hipMemsetAsync(ctx->st_aux.p, 0, (size_t)tile_waves * 24, ctx->stream));
     if (prof) HIP_TRY(hipMemsetAsync(ctx->st_aux.p, 0, rtg::TP_SLOTS * 8, ctx->stream));
     if (prof) HIP_TRY(hipMemsetAsync((unsigned long long*)ctx->st_aux.p + rtg::TP_W_FIRST_MIN, 0xFF, 8, ctx->stream));
     rtg::GatherParams gpt = gp;
@@ -1627,13 +1652,17 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     gpt.opt_range = std::min(0.5f, 0.1f + 1.5f / sqrtf((float)gp.k));
     if (const char* e = getenv("RT_GATHER_OPT_RANGE")) gpt.opt_range = (float)atof(e);      // tuning aids
     if (const char* e = getenv("RT_GATHER_MIN_LANES")) gpt.min_lanes = atoi(e);
+    if (const char* e = getenv("RT_GATHER_ACT_REACH")) gpt.act_reach = (float)atof(e);
     if (const char* e = getenv("RT_GATHER_ROUNDS")) gpt.max_rounds = atoi(e);
+    int part_tail = 2;
+    if (const char* e = getenv("RT_GATHER_PART_TAIL")) part_tail = std::max(0, atoi(e));
 
     // Subsurface materials: the group kernel forms their surface estimates and leaves them in the requests' records for the
     // per-request kernel, which therefore only runs after it (no launch alongside: a record being completed must not be read).
     const bool sss_scene = ctx->has_sss && !getenv("RT_SSS_PER_REQUEST");      // (the switch: comparison runs)
     rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, windows_done, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
-                     sss_scene ? 1 : 0, prof ? (unsigned long long*)ctx->st_aux.p : nullptr};
+                     sss_scene ? 1 : 0, prof ? (unsigned long long*)ctx->st_aux.p : nullptr, span ? (unsigned long long*)ctx->st_aux.p : nullptr,
+                     packed ? d_cont : nullptr, cont_cap, part_tail, getenv("RT_GATHER_QUEUE_ORDER") ? 0 : 1, pack_cap};
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));      // (the queue and the counters are ready here)
     if (packed && prof) hipLaunchKernelGGL(rtg::gather_stream_prof_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc, d_pack);
     else if (packed) hipLaunchKernelGGL(rtg::gather_stream_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc, d_pack);
@@ -1642,13 +1671,37 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     // The per-request kernel alongside, on the second stream.  Its waves stay only once every wave of the group kernel
     // has begun, so they never hold a place the group kernel waits for; six blocks per CU leave room for one of the
     // group kernel's in any case.
-    if (!sss_scene) {
+    const bool alongside = !sss_scene && !getenv("RT_GATHER_NO_ALONGSIDE");      // (the switch: comparison runs)
+    if (alongside) {
         HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         hipLaunchKernelGGL(rtg::gather_alongside_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->side, ctx->pm[0], ctx->pm[1], recs, d_redo,
                            (uint32_t)std::min<size_t>(redo_entries, 0xFFFFFFFFu), cnt, shard_cap, (const unsigned long long*)windows_done, (unsigned)tile_waves,
                            next_gather, gp, d_acc);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
+    }
+    if (span) {
+        std::vector<unsigned long long> v((size_t)tile_waves * 3);
+        HIP_TRY(hipMemcpyAsync(v.data(), ctx->st_aux.p, v.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int i = 0; i < tile_waves; i++) if (v[3 * i + 1]) { t0 = std::min(t0, v[3 * i]); t1 = std::max(t1, v[3 * i + 1]); }
+        std::vector<double> ends, begins;
+        double busy = 0;
+        unsigned long long idle_waves = 0, spins = 0, parts = 0;
+        for (int i = 0; i < tile_waves; i++) {
+            if (!v[3 * i + 1]) continue;
+            if (!(v[3 * i + 2] & 0xFFFFFFFFull)) idle_waves++;
+            spins += v[3 * i + 2] >> 32; parts += v[3 * i + 2] & 0xFFFFFFFFull;
+            ends.push_back((double)(v[3 * i + 1] - t0) / 100.0); begins.push_back((double)(v[3 * i] - t0) / 100.0);
+            busy += (double)(v[3 * i + 1] - v[3 * i]) / 100.0;
+        }
+        std::sort(ends.begin(), ends.end()); std::sort(begins.begin(), begins.end());
+        const size_t n = ends.size();
+        if (n) fprintf(stderr, "packed group gather, waves in time (us from the first wave's start): %zu waves (%llu took no window), span %.0f, mean wave %.0f; began: median %.0f, 90 %% %.0f, last %.0f; "
+                               "ended: 10 %% %.0f, 25 %% %.0f, median %.0f, 75 %% %.0f, 90 %% %.0f, 99 %% %.0f, last %.0f; %llu windows and parts taken, %llu polls for a part's entry\n",
+                       n, idle_waves, (double)(t1 - t0) / 100.0, busy / n, begins[n / 2], begins[n * 9 / 10], begins[n - 1], ends[n / 10], ends[n / 4], ends[n / 2], ends[n * 3 / 4], ends[n * 9 / 10],
+                       ends[n * 99 / 100], ends[n - 1], parts, spins);
     }
     if (prof) {
         unsigned long long v[rtg::TP_SLOTS];
@@ -1681,7 +1734,7 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     hipLaunchKernelGGL(rtg::gather_kernel, dim3(ctx->num_cus * 8), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], recs, d_redo,
                        (const unsigned long long*)n_redo, next_gather, gp, d_acc);
     HIP_TRY(hipGetLastError());
-    if (!sss_scene) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // what follows on the stream follows both
+    if (alongside) HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // what follows on the stream follows both
     return RT_OK;
 }
 

@@ -33,9 +33,11 @@
 
 namespace rtg {
 
-constexpr int S_PACK_CAP = 4096;      // photons the packed list of a wave holds (16 bytes each)
+constexpr int S_PACK_CAP = 8192;      // photons the packed list of a wave holds at most (16 bytes each); TileArgs::pack_cap is the size in use
 constexpr int S_ATTEMPTS = 7;         // guesses at the centre's radius per round before the round is handed on
 constexpr int S_FLIGHT = 8;           // 64-photon steps of a streaming loop whose loads are in flight together
+constexpr int CONT_SHARDS = 8;        // lists of window parts handed from wave to wave (TileArgs::cont)
+constexpr int S_LEVEL = 320;          // subtrees of one tree level a group's box may touch
 constexpr int S_CELL = 512;           // photons in the tree cell whose density gives the first guess
 
 // Per-wave LDS of the kernel: 12.5 KB, so that twelve waves share a CU.  The per-lane tables of the passes lie over
@@ -44,9 +46,9 @@ struct StreamLds {
     union {
         uint32_t table[(T_BINS / 2) * WAVE];      // histograms: [bin][32 words], two 16-bit counts each; critical bin: [T_CRIT][64]
         struct {
-            uint32_t leaf[T_LEAVES], piv[T_PIVOTS];           // as the walk lists them
-            int f_lo[FRONT], f_hi[FRONT];                     // the walk's frontier
-            uint32_t leaf_sorted[T_LEAVES], piv_sorted[T_PIVOTS];
+            uint32_t leaf[T_LEAVES], piv[T_PIVOTS];           // as the walk lists them: by tree level, left to right
+            int a_lo[S_LEVEL], a_hi[S_LEVEL];                 // the subtrees of the level being looked at
+            int b_lo[S_LEVEL], b_hi[S_LEVEL];                 // those of the level below, in the making
         } w;
     };
     float stage[9 * WAVE];                        // a step's photons: x[64] y[64] z[64] (+ power, direction in a sum pass); the radix histogram of step 1
@@ -63,67 +65,67 @@ __device__ __forceinline__ float4 load_global4(const float4* p)
     return float4{v.x, v.y, v.z, v.w};
 }
 
+__device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int src)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // ---- the walk: leaves and pivots inside the box [gl, gh] -> g_S.w.leaf / piv; n_leaf | n_piv << 16, or -1 when the
-// box touches more of the tree than the lists hold
+// box touches more of the tree than the lists hold.  The tree is taken level by level, every level from left to right
+// (a lane's children go to the next level's list side by side, in the lanes' order), so the lists come out ordered by
+// (level, tree position): two walks for different boxes list what they have in common in the same order, which is
+// what makes the packed list -- and the order of the sums over it -- a function of the final box alone.
 __device__ __attribute__((noinline)) int stream_walk(PhotonMapView pm, float glx, float gly, float glz, float ghx, float ghy, float ghz)
 {
     StreamLds& S = g_S;
     const int lane = lane_id();
-    int n_leaf = 0, n_piv = 0, nf = 1;
-    if (lane == 0) { S.w.f_lo[0] = 0; S.w.f_hi[0] = (int)pm.n; }
+    int n_leaf = 0, n_piv = 0, n_cur = 1;
+    int *c_lo = S.w.a_lo, *c_hi = S.w.a_hi, *x_lo = S.w.b_lo, *x_hi = S.w.b_hi;
+    if (lane == 0) { c_lo[0] = 0; c_hi[0] = (int)pm.n; }
     __builtin_amdgcn_wave_barrier();
-    while (nf > 0) {
-        const int take = nf < WAVE ? nf : WAVE;
-        const int base = nf - take;
-        nf = base;
-        int rlo = 0, rhi = 0;
-        if (lane < take) { rlo = S.w.f_lo[base + lane]; rhi = S.w.f_hi[base + lane]; }
-        const bool live = lane < take && rhi > rlo;
-        const bool small = live && rhi - rlo <= WAVE;
-        bool is_leaf = small;
-        if (is_leaf) {
-            const float* b = pm.leaf_box + 6 * (size_t)(rlo >> 5);
-            is_leaf = !(b[0] > ghx || b[3] < glx || b[1] > ghy || b[4] < gly || b[2] > ghz || b[5] < glz);
+    while (n_cur > 0) {
+        int n_next = 0;
+        for (int base = 0; base < n_cur; base += WAVE) {
+            const int take = n_cur - base < WAVE ? n_cur - base : WAVE;
+            int rlo = 0, rhi = 0;
+            if (lane < take) { rlo = c_lo[base + lane]; rhi = c_hi[base + lane]; }
+            const bool live = lane < take && rhi > rlo;
+            const bool small = live && rhi - rlo <= WAVE;
+            bool is_leaf = small;
+            if (is_leaf) {
+                const float* b = pm.leaf_box + 6 * (size_t)(rlo >> 5);
+                is_leaf = !(b[0] > ghx || b[3] < glx || b[1] > ghy || b[4] < gly || b[2] > ghz || b[5] < glz);
+            }
+            const bool is_inner = live && !small;
+            int mid = 0;
+            bool piv_in = false, go_l = false, go_r = false;
+            if (is_inner) {
+                mid = rlo + (rhi - rlo) / 2;
+                const float4 pv = pm.pos[mid];
+                const int ax = (int)pv.w;
+                piv_in = !(pv.x > ghx || pv.x < glx || pv.y > ghy || pv.y < gly || pv.z > ghz || pv.z < glz);
+                const float split = ax == 0 ? pv.x : (ax == 1 ? pv.y : pv.z);
+                const float lo_ax = ax == 0 ? glx : (ax == 1 ? gly : glz), hi_ax = ax == 0 ? ghx : (ax == 1 ? ghy : ghz);
+                go_l = lo_ax <= split && mid > rlo;           // the left side holds coordinates <= split
+                go_r = hi_ax >= split && rhi > mid + 1;       // the right side holds coordinates >= split
+            }
+            const unsigned long long m_leaf = __ballot(is_leaf), m_piv = __ballot(piv_in), m_l = __ballot(go_l), m_r = __ballot(go_r);
+            const int c_leaf = __builtin_popcountll(m_leaf), c_piv = __builtin_popcountll(m_piv), c_l = __builtin_popcountll(m_l), c_r = __builtin_popcountll(m_r);
+            if (n_leaf + c_leaf > T_LEAVES || n_piv + c_piv > T_PIVOTS || n_next + c_l + c_r > S_LEVEL) return -1;
+            if (is_leaf) S.w.leaf[n_leaf + (int)prefix_rank(m_leaf)] = ((uint32_t)rlo << 7) | (uint32_t)(rhi - rlo);
+            if (piv_in) S.w.piv[n_piv + (int)prefix_rank(m_piv)] = (uint32_t)mid;
+            const int at = n_next + (int)prefix_rank(m_l) + (int)prefix_rank(m_r);      // children of the lanes before this one
+            if (go_l) { x_lo[at] = rlo; x_hi[at] = mid; }
+            if (go_r) { x_lo[at + (go_l ? 1 : 0)] = mid + 1; x_hi[at + (go_l ? 1 : 0)] = rhi; }
+            n_leaf += c_leaf; n_piv += c_piv; n_next += c_l + c_r;
         }
-        const bool is_inner = live && !small;
-        int mid = 0;
-        bool piv_in = false, go_l = false, go_r = false;
-        if (is_inner) {
-            mid = rlo + (rhi - rlo) / 2;
-            const float4 pv = pm.pos[mid];
-            const int ax = (int)pv.w;
-            piv_in = !(pv.x > ghx || pv.x < glx || pv.y > ghy || pv.y < gly || pv.z > ghz || pv.z < glz);
-            const float split = ax == 0 ? pv.x : (ax == 1 ? pv.y : pv.z);
-            const float lo_ax = ax == 0 ? glx : (ax == 1 ? gly : glz), hi_ax = ax == 0 ? ghx : (ax == 1 ? ghy : ghz);
-            go_l = lo_ax <= split && mid > rlo;           // the left side holds coordinates <= split
-            go_r = hi_ax >= split && rhi > mid + 1;       // the right side holds coordinates >= split
-        }
-        const unsigned long long m_leaf = __ballot(is_leaf), m_piv = __ballot(piv_in), m_l = __ballot(go_l), m_r = __ballot(go_r);
-        const int c_leaf = __builtin_popcountll(m_leaf), c_piv = __builtin_popcountll(m_piv), c_l = __builtin_popcountll(m_l), c_r = __builtin_popcountll(m_r);
         __builtin_amdgcn_wave_barrier();
-        if (n_leaf + c_leaf > T_LEAVES || n_piv + c_piv > T_PIVOTS || nf + c_l + c_r > FRONT) return -1;
-        if (is_leaf) S.w.leaf[n_leaf + (int)prefix_rank(m_leaf)] = ((uint32_t)rlo << 7) | (uint32_t)(rhi - rlo);
-        if (piv_in) S.w.piv[n_piv + (int)prefix_rank(m_piv)] = (uint32_t)mid;
-        if (go_l) { const int p = nf + (int)prefix_rank(m_l); S.w.f_lo[p] = rlo; S.w.f_hi[p] = mid; }
-        if (go_r) { const int p = nf + c_l + (int)prefix_rank(m_r); S.w.f_lo[p] = mid + 1; S.w.f_hi[p] = rhi; }
-        n_leaf += c_leaf; n_piv += c_piv; nf += c_l + c_r;
-        __builtin_amdgcn_wave_barrier();
+        int* t = c_lo; c_lo = x_lo; x_lo = t;
+        t = c_hi; c_hi = x_hi; x_hi = t;
+        n_cur = n_next;
     }
     return n_leaf | (n_piv << 16);
-}
-
-// dst[rank of src[i] among src[0..n)] = src[i]: the entries are distinct (tree positions), n is a few hundred
-__device__ __forceinline__ void rank_sort(const uint32_t* src, uint32_t* dst, int n)
-{
-    const int lane = lane_id();
-    for (int i0 = 0; i0 < n; i0 += WAVE) {
-        const int i = i0 + lane;
-        const uint32_t e = src[i < n ? i : n - 1];
-        int rank = 0;
-#pragma unroll 4
-        for (int j = 0; j < n; j++) rank += src[j] < e ? 1 : 0;
-        if (i < n) dst[rank] = e;
-    }
 }
 
 // Step s of a pair of lists (leaves, pivots): lane j's tree position (clamped to a valid one) and the photons in the step.
@@ -154,8 +156,8 @@ __device__ __forceinline__ float4 pack_step(const float4* pack, int s, int n_pac
 constexpr int C_BINS = 256;
 __device__ __forceinline__ uint32_t* centre_hist() { return reinterpret_cast<uint32_t*>(g_S.stage); }
 __device__ __forceinline__ int centre_bin(float d2, float hscale) { const int b = (int)(d2 * hscale); return b < C_BINS - 1 ? b : C_BINS - 1; }
-__device__ __attribute__((noinline)) int pack_listed(const float4* __restrict__ pos, float4* pack, float cx, float cy, float cz, float reach2, float lim, int n_leaf, int n_piv,
-                                                     int* inside)
+__device__ __attribute__((noinline)) int pack_listed(const float4* __restrict__ pos, float4* pack, int pack_cap, float cx, float cy, float cz, float reach2, float lim, int n_leaf,
+                                                     int n_piv, int* inside)
 {
     const int lane = lane_id();
     uint32_t* const hist = centre_hist();
@@ -173,7 +175,7 @@ __device__ __attribute__((noinline)) int pack_listed(const float4* __restrict__ 
         int at[S_FLIGHT], n[S_FLIGHT];
 #pragma unroll
         for (int u = 0; u < S_FLIGHT; u++) {
-            at[u] = list_step(g_S.w.leaf_sorted, g_S.w.piv_sorted, s0 + u < n_steps ? s0 + u : n_steps - 1, n_leaf, n_piv, lane, n[u]);
+            at[u] = list_step(g_S.w.leaf, g_S.w.piv, s0 + u < n_steps ? s0 + u : n_steps - 1, n_leaf, n_piv, lane, n[u]);
             if (s0 + u >= n_steps) n[u] = 0;
             p[u] = load_global4(pos + at[u]);
         }
@@ -184,7 +186,7 @@ __device__ __attribute__((noinline)) int pack_listed(const float4* __restrict__ 
             const bool keep = lane < n[u] && d2 <= reach2;
             const unsigned long long m = __ballot(keep);
             const int c = __builtin_popcountll(m);
-            if (out + c > S_PACK_CAP) return -1;
+            if (out + c > pack_cap) return -1;
             if (keep) pack[out + (int)prefix_rank(m)] = float4{p[u].x, p[u].y, p[u].z, __uint_as_float((uint32_t)at[u])};
             out += c;
             const bool in = lane < n[u] && d2 < lim;
@@ -615,10 +617,23 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
 {
     uint32_t* const cell = g_S.table;
     const int lane = lane_id();
-    float4* const pack = pack_all + (size_t)blockIdx.x * S_PACK_CAP;
+    float4* const pack = pack_all + (size_t)blockIdx.x * (size_t)ta.pack_cap;
     const rtq::Map map = rtq::map_units(ta.cnt, ta.shard_cap, WAVE);
     const uint32_t n_windows = map.total;
+    // draws of the window counter that may name a window: with late_first, places in the longest shard x shards
+    uint32_t n_draws = n_windows;
+    if (ta.late_first) {
+        const uint32_t units = lane < rtq::SHARDS ? (map.n + WAVE - 1) / WAVE : 0u;
+        n_draws = (uint32_t)wave_max_f((float)units) * rtq::SHARDS;      // (window counts are far below 2^24: exact in float)
+    }
     if (lane == 0) atomicAdd(ta.windows_done + 1, 1ull);
+    const unsigned long long span_begin = ta.span ? wall_clock64() : 0ull;
+    unsigned span_windows = 0, span_spins = 0;
+    // Parts of windows are handed from wave to wave (TileArgs::cont) only while the kernel is drawing its last windows:
+    // before that every wave has work anyway.  One list per CONT_SHARDS-th of the waves, so that the words the waves
+    // count on are spread (a single word takes some sixty additions a microsecond).
+    unsigned long long* const my_cont = ta.cont ? ta.cont + (size_t)(blockIdx.x % CONT_SHARDS) * (4 + 2 * (size_t)ta.cont_cap) : nullptr;
+    bool sharing = false;
     unsigned long long pr[TP_SLOTS] = {};      // (dead, and gone, in the instantiation without the accounting)
     const unsigned long long t_begin = PROF ? clock64() : 0ull;
     const float r_max = sqrtf(gp.r2);
@@ -626,11 +641,55 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
 #define TILE_PROF(slot, expr) do { if (PROF) { const unsigned long long t_ = clock64(); expr; pr[slot] += clock64() - t_; } else { expr; } } while (0)
 #define TILE_COUNT(slot, cond) do { if (PROF) pr[slot] += __builtin_popcountll(__ballot(cond)); } while (0)
     while (true) {
-        unsigned long long w0 = 0;
-        if (lane == 0) w0 = atomicAdd(ta.next, 1ull);
-        const uint32_t win = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)w0);
-        const uint32_t win_hi = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(w0 >> 32));
-        if (win_hi || win >= n_windows) break;       // (the high half is zero for any real queue)
+        // ---- what to work on: a part of a window that another wave (or this one) has handed on, else the next window
+        unsigned long long c_mask = 0, c_word = 0;
+        if (sharing && lane == 0) {
+            // (every access a read-modify-write -- a count read by adding zero: those are served in a few microseconds, where a
+            // device-coherent load of a word that other waves keep changing was measured to take 150 and more; and no
+            // compare-and-swap loops: with a part per window, as at k = 100, hundreds of waves retrying took 8 us per part)
+            if ((long long)atomicAdd(my_cont + 1, 0ull) > 0) {
+                if ((long long)atomicAdd(my_cont + 1, ~0ull) > 0) {
+                    const unsigned long long h = atomicAdd(my_cont, 1ull);
+                    // announced only once written, and the announcements before it were for entries before it -- though such
+                    // an entry's own writer may be a moment behind: a short wait at most.  Taken and zeroed in one.
+                    unsigned long long* const e = my_cont + 4 + 2 * h;
+                    while (!(c_mask = atomicExch(e, 0ull))) { __builtin_amdgcn_s_sleep(2); span_spins++; }
+                    while (!(c_word = atomicExch(e + 1, 0ull))) { __builtin_amdgcn_s_sleep(2); span_spins++; }
+                } else {
+                    atomicAdd(my_cont + 1, 1ull);      // (another wave was quicker: the count goes back up)
+                }
+            }
+        }
+        c_word = bcast64(c_word, 0);
+        c_mask = bcast64(c_mask, 0);
+        const bool part = c_word != 0;                // a handed-on part: its window, the lanes waiting, the rounds the window has had
+        const int round_first = part ? (int)((c_word >> 32) & 0xFFu) : 0;
+        uint32_t win;
+        if (part) {
+            win = (uint32_t)c_word;
+            sharing = true;
+        } else {
+            unsigned long long w0 = 0;
+            if (lane == 0) w0 = atomicAdd(ta.next, 1ull);
+            const uint32_t drawn = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)w0);
+            const uint32_t drawn_hi = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(w0 >> 32));
+            if (drawn_hi || drawn >= n_draws) break;     // (the high half is zero for any real queue); parts handed on later stay with their wave
+            sharing = ta.cont != nullptr && (unsigned long long)drawn + (unsigned long long)ta.part_tail * gridDim.x >= n_draws;
+            if (ta.late_first) {
+                // The shards' windows from the last appended to the first, the shards taken in turn: what the later shading
+                // passes queued -- hit points of rays that left a refracting or reflecting surface, scattered where a tile of
+                // camera rays lands in one patch -- makes the windows of several rounds and most of the requests handed on,
+                // and those are best met while every wave still has work to turn to.
+                const int s = (int)(drawn % rtq::SHARDS);
+                const uint32_t j = drawn / rtq::SHARDS;
+                const uint32_t units_s = (__shfl(map.n, s) + WAVE - 1) / WAVE;
+                if (j >= units_s) continue;               // (a shorter shard than the longest: nothing at this place)
+                win = __shfl(map.incl, s) - 1 - j;
+            } else {
+                win = drawn;
+            }
+        }
+        span_windows++;
         unsigned shard;
         uint32_t first, n_shard;
         rtq::locate(map, win, WAVE, shard, first, n_shard);
@@ -645,6 +704,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
         const bool sss = (flags & GATHER_SSS) != 0;
         bool redo = have && ((flags & ~(GATHER_SSS | GATHER_MARCH)) != 0 || (sss && !ta.sss_surface) || ta.all_redo || pm.n >= (1ll << 24));
         bool todo = have && !redo;
+        if (part) { redo = false; todo = have && ((c_mask >> lane) & 1ull) != 0; }      // (the parts before this one saw to the other lanes)
         if (PROF) pr[TP_WINDOWS]++;
         TILE_COUNT(TP_R_FLAGS, redo);
         const unsigned long long t_window = PROF ? clock64() : 0ull;
@@ -653,8 +713,10 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
         // each round takes the requests close to one of those still waiting; what is left after the last round, and
         // rounds of only a few requests, go to the per-request kernel.
         const int ROUNDS = gp.max_rounds;
-        const int MIN_LANES = gp.min_lanes > 0 ? gp.min_lanes : (gp.k >= 400 ? 12 : 6);
-        for (int round = 0; round < ROUNDS; round++) {
+        // (the fewest requests worth a round: measured on the water frame with windows taken late-first and parts handed on --
+        // k = 1000: 1 / 2 / 4 / 6 / 8 / 12 requests give 8.3 / 8.1 / 8.0 / 7.4 / 7.5 / 7.6 ms; k = 100: 1 / 2 / 4 / 6 / 8 give 4.7 / 4.8 / 4.9 / 5.0 / 5.1)
+        const int MIN_LANES = gp.min_lanes > 0 ? gp.min_lanes : (gp.k >= 400 ? 6 : 1);
+        for (int round = round_first; round < ROUNDS; round++) {
             const unsigned long long m_todo = __ballot(todo);
             if (!m_todo) break;
             // ---- the round's centre: the middle one of the requests waiting
@@ -678,7 +740,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                 continue;
             }
             // ---- 1. the centre's k-th distance r_c (< 0: fewer than k photons within the search radius)
-            float r_c = -1.f;
+            float r_c = -1.f, R_found = 0.f;
             int n_pack = 0;
             bool found = false;
             {
@@ -712,11 +774,9 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                         continue;
                     }
                     const int n_leaf = lists & 0xFFFF, n_piv = lists >> 16;
-                    TILE_PROF(TP_C_SORT, rank_sort(g_S.w.leaf, g_S.w.leaf_sorted, n_leaf); rank_sort(g_S.w.piv, g_S.w.piv_sorted, n_piv));
-                    __builtin_amdgcn_wave_barrier();
                     const float lim = whole ? gp.r2 : R * R;
                     int packed, inside = 0;
-                    TILE_PROF(TP_C_PACK, packed = pack_listed(pm.pos, pack, cx, cy, cz, reach * reach * 1.0001f, lim, n_leaf, n_piv, &inside));
+                    TILE_PROF(TP_C_PACK, packed = pack_listed(pm.pos, pack, ta.pack_cap, cx, cy, cz, reach * reach * 1.0001f, lim, n_leaf, n_piv, &inside));
                     __builtin_amdgcn_wave_barrier();
                     if (packed < 0) {
                         if (PROF) pr[TP_A_PACK]++;
@@ -746,6 +806,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                     }
                     n_pack = packed;
                     found = true;
+                    R_found = R;
                     r_c = inside >= gp.k ? sqrtf(__uint_as_float(bits)) : -1.f;      // (fewer than k: only within the search radius itself)
                 }
                 if (PROF) pr[TP_KTH] += clock64() - t_kth;
@@ -760,7 +821,8 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
             float bound = gp.r2, lower = 0.f;
             if (r_c >= 0.f) {
                 prev_r = r_c;
-                act = todo && d_c <= r_c;                            // this round: the requests inside the centre's own ball
+                // this round: the requests inside the centre's own ball and a little beyond, as far as the packed list reaches
+                act = todo && d_c <= fminf(r_c * gp.act_reach, R_found);
                 // r_k(q) lies within |q - q_c| of r_c (triangle inequality).  For a request far from the centre that
                 // range is wide while the photon density, and with it r_k, changes little over a ball's width: such a
                 // request is given the range r_c * (1 -+ opt_range) instead.  Both ends are checked by the counts below
@@ -784,6 +846,29 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                 continue;
             }
             todo = todo && !act;
+            // The requests still waiting become a part of their own, for whichever wave is free first (this one, if none is
+            // sooner): a window of several patches -- a tile across a silhouette -- is then worked on by several waves at once
+            // instead of holding one wave, and the kernel's end, for several rounds.  What a round computes depends on the
+            // window and the lanes waiting alone, so the results do not depend on who takes the part.
+            {
+                const unsigned long long m_left = __ballot(todo);
+                if (sharing && m_left && round + 1 < ROUNDS) {
+                    unsigned long long at = ~0ull;
+                    if (lane == 0) {
+                        at = atomicAdd(my_cont + 2, 1ull);
+                        if (at < ta.cont_cap) {
+                            // (one part more to finish before the window counts as done: noted before this part is)
+                            atomicAdd(ta.windows_done, ~0ull);
+                            __hip_atomic_store(my_cont + 4 + 2 * at, m_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(my_cont + 5 + 2 * at, (unsigned long long)win | ((unsigned long long)(round + 1) << 32) | (1ull << 63), __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                            atomicAdd(my_cont + 1, 1ull);
+                        }
+                    }
+                    at = bcast64(at, 0);
+                    if (at < ta.cont_cap) todo = false;      // (a full list: the rounds stay here)
+                }
+            }
             // ---- 2. the packed list cut down to the box around the round's balls and the centre's reach: what it holds now
             // depends on the window alone
             {
@@ -917,6 +1002,11 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
     }
 #undef TILE_PROF
 #undef TILE_COUNT
+    if (ta.span && lane == 0) {
+        ta.span[3 * (size_t)blockIdx.x] = span_begin;
+        ta.span[3 * (size_t)blockIdx.x + 1] = wall_clock64();
+        ta.span[3 * (size_t)blockIdx.x + 2] = span_windows | ((unsigned long long)span_spins << 32);
+    }
     if (PROF && lane == 0) {
         pr[TP_BUSY] = clock64() - t_begin;
 #pragma unroll

@@ -80,6 +80,16 @@ struct TileArgs {
     int sss_surface;                 // nonzero: form the surface estimate of subsurface requests here and hand the rest on (the per-request
                                      // kernel must then run AFTER this one: the result travels in the request's record)
     unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
+    unsigned long long* span;        // optional (development aid): per wave of the packed form, when it began and ended (100 MHz clock) and the windows it took
+    // The packed form's lists of window parts handed from wave to wave (see gather_stream_body), CONT_SHARDS of them, each:
+    // [0] entries taken, [1] entries written and not yet taken (signed), [2] entries reserved, [3] unused, then two words
+    // per entry -- the lanes still waiting (never zero), and window | round << 32 | 1 << 63.  Entries are zero until
+    // written and zeroed again by the wave that takes them.  Null: rounds stay with their wave.
+    unsigned long long* cont;
+    unsigned cont_cap;               // entries one list holds
+    int part_tail;                   // parts are handed on while the kernel draws its last part_tail x (waves of the grid) windows
+    int late_first;                  // packed form: windows are taken from each shard's last to its first (see gather_stream_body)
+    int pack_cap;                    // photons a wave's packed list holds (<= S_PACK_CAP)
 };
 enum TileProf { TP_WINDOWS, TP_ROUNDS, TP_LANES, TP_STEPS, TP_KTH, TP_WALK, TP_HIST, TP_CRIT, TP_RANK, TP_SUM, TP_N_HIST, TP_N_CRIT, TP_N_SUM,
                 TP_R_FLAGS, TP_R_FEW, TP_R_WALK, TP_R_SHORT, TP_R_CROWD, TP_R_LEFT, TP_R_TIE,      // TP_R_*: requests handed on, by reason
