@@ -266,7 +266,7 @@ int rt_knn_estimate_grouped(rt_context* ctx, const rt_render_params* p, int64_t 
 /* No counterpart in the reference.  rt_knn_estimate_grouped for callers that cannot allocate device memory -- code
  * under HIP graph capture, tight serving loops, harnesses that forbid it: requests and results live in the caller's
  * device buffers (d_pos / d_normal / d_color: n x 3 doubles; d_rgb: n x 3 doubles out), and every byte of working
- * memory (request queue, hand-over list, counters) is a fixed array inside the library, about 7.7 MB on each GPU it
+ * memory (request queue, hand-over list, packed photon lists of 512 waves, counters) is a fixed array inside the library, about 41 MB on each GPU it
  * runs on, held until the process ends.  The call makes no hipMalloc / hipFree; it is enqueued on the context's
  * stream and not synchronised.  n <= RT_NOALLOC_MAX_REQUESTS, more is refused with RT_ERR_LIMIT.  Every call on a
  * GPU shares that GPU's array, whichever context it comes through: two calls overlapping in time on one GPU would
@@ -299,6 +299,26 @@ int rt_render_rows(rt_context* ctx, const rt_camera* cam, const rt_render_params
  * is complete.  (Processes with one GPU each gather over RCCL instead, see raytracer_amd/tiling.py.) */
 int rt_gather_rows(rt_context* const* ctxs, const void* const* d_parts, int n_parts, int band_rows, int height, size_t row_bytes,
                    void* d_frame);
+
+/* ---- device: one process per GPU ----------------------------------------------------------- */
+/* Frame assembly over PROCESSES, one GPU each, for hosts written against this header (Python hosts use
+ * torch.distributed, raytracer_amd/tiling.py; both are the join of the reference's render threads, main.cpp:862).
+ * Rank r of n_ranks traces part r of the row interleave (rt_render_params.band_rows / n_parts / part) into a compact
+ * device buffer; rt_gather_frame sends it to rank 0 over RCCL -- every peer over its own xGMI link, one grouped
+ * send/receive, no ring -- and rank 0 puts every band in its place in d_frame.  RCCL (librccl.so.1) is loaded when the
+ * first of these calls is made and by nothing else in the library; without it they return RT_ERR_STATE.
+ *   rt_comm_unique_id   rank 0 makes the 128-byte id; the host hands it to the other ranks by whatever channel it has
+ *   rt_comm_create      collective over the n_ranks processes; the communicator is bound to ctx's device and stream
+ *   rt_gather_frame     collective; d_part: height / n_ranks rows of row_bytes (this rank's bands, compact); d_frame:
+ *                       height rows of row_bytes on rank 0, ignored elsewhere; height must be a multiple of
+ *                       band_rows * n_ranks.  Enqueued on ctx's stream behind the kernels that traced the part, not
+ *                       synchronised; rank 0 keeps a staging buffer of (n_ranks - 1) parts between calls. */
+typedef struct rt_comm rt_comm;
+#define RT_COMM_ID_BYTES 128
+int rt_comm_unique_id(unsigned char id[RT_COMM_ID_BYTES]);
+int rt_comm_create(rt_context* ctx, const unsigned char id[RT_COMM_ID_BYTES], int rank, int n_ranks, rt_comm** out);
+void rt_comm_destroy(rt_comm* comm);
+int rt_gather_frame(rt_comm* comm, const void* d_part, int band_rows, int height, size_t row_bytes, void* d_frame);
 
 /* ---- host I/O either side of the path ---------------------------------------------------- */
 

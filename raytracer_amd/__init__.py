@@ -348,6 +348,43 @@ def gather_rows(ctxs, d_parts, band_rows, height, row_bytes, d_frame):
     _chk(lib.rt_gather_rows(hs, ps, n, band_rows, height, row_bytes, d_frame), "rt_gather_rows")
 
 
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """rt_comm_unique_id: the 128-byte id rank 0 makes and hands to the other ranks (bytes)."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    _chk(lib.rt_comm_unique_id(buf), "rt_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """The ranks of a job, one process and one GPU each, joined over RCCL through the C ABI (rt_comm_create: collective)."""
+
+    def __init__(self, ctx, comm_id, rank, n_ranks):
+        if len(comm_id) != COMM_ID_BYTES:
+            raise ValueError("the id is %d bytes" % COMM_ID_BYTES)
+        self.h = _lib.vp()
+        self.ctx, self.rank, self.n_ranks = ctx, rank, n_ranks
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(comm_id)
+        _chk(lib.rt_comm_create(ctx.h, buf, rank, n_ranks, ctypes.byref(self.h)), "rt_comm_create")
+
+    def gather_frame(self, d_part, band_rows, height, row_bytes, d_frame=None):
+        """rt_gather_frame (collective): this rank's compact bands d_part -> the frame d_frame on rank 0 (device pointers)."""
+        _chk(lib.rt_gather_frame(self.h, d_part, band_rows, height, row_bytes, d_frame), "rt_gather_frame")
+
+    def close(self):
+        if self.h:
+            lib.rt_comm_destroy(self.h)
+            self.h = _lib.vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def save_bmp(path, rgb, dpi=72):
     rgb = _f64(rgb)
     h, w = rgb.shape[0], rgb.shape[1]

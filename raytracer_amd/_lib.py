@@ -100,6 +100,10 @@ PROTOTYPES = {
     "rt_render_rows_dev": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, vp, vp, P(Stats)]),
     "rt_render_rows": (c_i, [vp, P(Camera), P(RenderParams), c_i, c_i, P(c_d), P(c_u8), P(Stats)]),
     "rt_gather_rows": (c_i, [P(vp), P(vp), c_i, c_i, c_i, ctypes.c_size_t, vp]),
+    "rt_comm_unique_id": (c_i, [P(c_u8)]),
+    "rt_comm_create": (c_i, [vp, P(c_u8), c_i, c_i, P(vp)]),
+    "rt_comm_destroy": (None, [vp]),
+    "rt_gather_frame": (c_i, [vp, vp, c_i, c_i, ctypes.c_size_t, vp]),
     "rt_save_bmp": (c_i, [ctypes.c_char_p, c_i, c_i, c_i, P(c_d)]),
     "rt_save_bmp_bgr8": (c_i, [ctypes.c_char_p, c_i, c_i, c_i, P(c_u8)]),
 }

@@ -1,5 +1,7 @@
 // C ABI implementation: contexts, scene upload and kernel launches (see include/rt_amd.h).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // (types and signatures only: the library is bound at run time, see rccl_load)
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -2157,6 +2159,145 @@ int rt_gather_rows(rt_context* const* ctxs, const void* const* d_parts, int n_pa
         HIP_TRY(hipStreamSynchronize(ctxs[r]->stream));
     }
     return use_device(ctxs[0]);
+    });
+}
+
+// ---------------------------------------------------------------- one process per GPU: the frame over RCCL
+}  // extern "C"
+
+namespace {
+// RCCL's entry points, bound when first needed: the library itself does not link against RCCL, so processes that never
+// gather across ranks load nothing, and a Python host keeps the one copy its torch brought along.
+struct Rccl {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+
+int rccl_load()
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mu);
+    if (g_rccl.ok) return RT_OK;
+    if (!g_rccl.lib) {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL))) break;
+    }
+    if (!g_rccl.lib) return fail(RT_ERR_STATE, "RCCL is not available: %s", dlerror());
+#define RT_RCCL_SYM(field, sym)                                                                                   \
+    if (!(g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, #sym)))) return fail(RT_ERR_STATE, "RCCL lacks " #sym)
+    RT_RCCL_SYM(get_unique_id, ncclGetUniqueId);
+    RT_RCCL_SYM(comm_init_rank, ncclCommInitRank);
+    RT_RCCL_SYM(comm_destroy, ncclCommDestroy);
+    RT_RCCL_SYM(group_start, ncclGroupStart);
+    RT_RCCL_SYM(group_end, ncclGroupEnd);
+    RT_RCCL_SYM(send, ncclSend);
+    RT_RCCL_SYM(recv, ncclRecv);
+    RT_RCCL_SYM(error_string, ncclGetErrorString);
+#undef RT_RCCL_SYM
+    g_rccl.ok = true;
+    return RT_OK;
+}
+#define RCCL_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t r_ = (expr);                                                                              \
+        if (r_ != ncclSuccess) return fail(RT_ERR_HIP, "%s failed: %s", #expr, g_rccl.error_string(r_));       \
+    } while (0)
+}  // namespace
+
+struct rt_comm {
+    rt_context* ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, n_ranks = 1;
+    DevBuf stage;      // rank 0: the other ranks' parts as they arrive, compact
+};
+static_assert(sizeof(ncclUniqueId) == RT_COMM_ID_BYTES, "the id travels as RT_COMM_ID_BYTES bytes");
+
+extern "C" {
+
+int rt_comm_unique_id(unsigned char id[RT_COMM_ID_BYTES])
+{
+    return guarded([&]() -> int {
+    if (!id) return fail(RT_ERR_INVALID, "null argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    ncclUniqueId u;
+    RCCL_TRY(g_rccl.get_unique_id(&u));
+    memcpy(id, &u, RT_COMM_ID_BYTES);
+    return RT_OK;
+    });
+}
+
+int rt_comm_create(rt_context* ctx, const unsigned char id[RT_COMM_ID_BYTES], int rank, int n_ranks, rt_comm** out)
+{
+    return guarded([&]() -> int {
+    if (!ctx || !id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return fail(RT_ERR_INVALID, "bad argument");
+    int rc = rccl_load();
+    if (rc) return rc;
+    if ((rc = use_device(ctx))) return rc;
+    ncclUniqueId u;
+    memcpy(&u, id, RT_COMM_ID_BYTES);
+    rt_comm* c = new rt_comm;
+    c->ctx = ctx; c->rank = rank; c->n_ranks = n_ranks;
+    ncclResult_t r = g_rccl.comm_init_rank(&c->comm, n_ranks, u, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return fail(RT_ERR_HIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, n_ranks, g_rccl.error_string(r));
+    }
+    *out = c;
+    return RT_OK;
+    });
+}
+
+void rt_comm_destroy(rt_comm* comm)
+{
+    if (!comm) return;
+    if (comm->ctx) (void)hipSetDevice(comm->ctx->device);
+    if (comm->comm && g_rccl.ok) (void)g_rccl.comm_destroy(comm->comm);
+    comm->stage.release();
+    delete comm;
+}
+
+int rt_gather_frame(rt_comm* comm, const void* d_part, int band_rows, int height, size_t row_bytes, void* d_frame)
+{
+    return guarded([&]() -> int {
+    if (!comm || !comm->ctx || !d_part || band_rows < 1 || height < 1 || row_bytes == 0) return fail(RT_ERR_INVALID, "bad argument");
+    const int n = comm->n_ranks;
+    if (height % (band_rows * n) != 0) return fail(RT_ERR_INVALID, "row interleave band_rows %d n_parts %d does not tile height %d", band_rows, n, height);
+    if (comm->rank == 0 && !d_frame) return fail(RT_ERR_INVALID, "rank 0 needs the frame");
+    rt_context* ctx = comm->ctx;
+    int rc = use_device(ctx);
+    if (rc) return rc;
+    const size_t band_bytes = (size_t)band_rows * row_bytes;
+    const size_t n_bands = (size_t)height / ((size_t)band_rows * n);      // per part
+    const size_t part_bytes = band_bytes * n_bands;
+    if (comm->rank == 0 && n > 1 && (rc = comm->stage.reserve(part_bytes * (size_t)(n - 1)))) return rc;
+    if (n > 1) {
+        // one grouped exchange: every peer sends its part straight to rank 0 (point-to-point over its own link)
+        RCCL_TRY(g_rccl.group_start());
+        if (comm->rank == 0) {
+            for (int r = 1; r < n; r++) RCCL_TRY(g_rccl.recv((char*)comm->stage.p + part_bytes * (size_t)(r - 1), part_bytes, ncclUint8, r, comm->comm, ctx->stream));
+        } else {
+            RCCL_TRY(g_rccl.send(d_part, part_bytes, ncclUint8, 0, comm->comm, ctx->stream));
+        }
+        RCCL_TRY(g_rccl.group_end());
+    }
+    if (comm->rank == 0) {
+        // band b of part r is band b * n + r of the frame: one strided copy per part, behind the exchange on the stream
+        for (int r = 0; r < n; r++) {
+            const void* src = r == 0 ? d_part : (const void*)((const char*)comm->stage.p + part_bytes * (size_t)(r - 1));
+            HIP_TRY(hipMemcpy2DAsync((char*)d_frame + (size_t)r * band_bytes, band_bytes * n, src, band_bytes, band_bytes, n_bands, hipMemcpyDeviceToDevice, ctx->stream));
+        }
+    }
+    return RT_OK;
     });
 }
 

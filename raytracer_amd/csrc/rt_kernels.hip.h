@@ -487,6 +487,9 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
                 if (shadow_ids) shadow_ids[px] = sid;
                 else if (a.shadow == 2 && sid >= 0) ids[px] = id | SHADOWED_BIT;      // folded form: one word per pixel
             }
+#ifdef RT_TILE_END_TIMES
+            if (t_out) t_out[px] = (double)wall_clock64();      // (measurement build: when the pixel's wave was done)
+#endif
         }
     }
     if (overflow) { atomicMax(&ctr->overflow, 1ull); latch_overflow(ctr, 0); }
