@@ -577,7 +577,7 @@ def other_configs(rt, ctx, torch, dev, prof_all, skip_c5=False):
     tf = gflop / (gather_ms * 1e-3) / 1e12
     out["water_photon_map_1920x1080_k1000"]["roofline"] = {
         "bound": "valu", "achieved": round(tf, 3), "peak": VALU_PEAK_TFLOPS["f64"], "unit": "TFLOP/s", "frac": round(tf / VALU_PEAK_TFLOPS["f64"], 4),
-        "kernels": "gather_tile_kernel + gather_kernel", "kernels_ms": round(gather_ms, 3), "flop_per_query": k * 38, "bytes_per_query": k * 36,
+        "kernels": "gather_stream_kernel + gather_alongside_kernel + gather_kernel", "kernels_ms": round(gather_ms, 3), "flop_per_query": k * 38, "bytes_per_query": k * 36,
         "hbm_priced": {"GBps": round(gbytes / (gather_ms * 1e-3) / 1e9, 1), "ratio_to_hbm_peak": round(gbytes / (gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 3),
                        "note": "the 45 MB photon map stays in the Infinity Cache"}}
     # the per-photon term is evaluated in float by both gather kernels: the same arithmetic against the float vector rate

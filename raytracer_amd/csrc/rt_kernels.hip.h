@@ -455,7 +455,14 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
             R o[3] = {(R)a.cam_pos[0], (R)a.cam_pos[1], (R)a.cam_pos[2]};
             R d[3] = {(R)dd.x, (R)dd.y, (R)dd.z};
             R dist = R(1e9);
+#ifdef RT_TILE_END_TIMES
+            const unsigned long long c_begin = clock64();
+#endif
             int id = trace_ray<R, COUNT, TRI_ONLY, MODE>(sv, o, d, dist, st, &overflow, &wc);
+#ifdef RT_TILE_END_TIMES
+            __builtin_amdgcn_wave_barrier();
+            const unsigned long long c_mid = clock64();
+#endif
             long long px = (long long)yl * a.width + x;
             ids[px] = id;
             if (t_out) t_out[px] = (double)dist;
@@ -488,7 +495,9 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
                 else if (a.shadow == 2 && sid >= 0) ids[px] = id | SHADOWED_BIT;      // folded form: one word per pixel
             }
 #ifdef RT_TILE_END_TIMES
-            if (t_out) t_out[px] = (double)wall_clock64();      // (measurement build: when the pixel's wave was done)
+            // (measurement build: when the pixel's wave was done; RT_TILE_PHASES: cycles of the camera phase in the even
+            // columns, of the shadow phase in the odd ones)
+            if (t_out) t_out[px] = a.part == -7 ? (double)((x & 1) ? clock64() - c_mid : c_mid - c_begin) : (double)wall_clock64();
 #endif
         }
     }
