@@ -698,14 +698,32 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + 4 * a4, sort_bytes, k0, k1, v0, v1, ne, 0, rte::EMIT_ORDER_KEY_BITS, ctx->stream));
             order = v1;
         }
+        // RT_EMIT_RESORT=1: the survivors of every bounce ordered by direction and starting point before the next (comparison runs)
+        const bool resort = getenv("RT_EMIT_RESORT") != nullptr && a.n_emit >= 4096;
+        uint32_t *sk0 = nullptr, *sk1 = nullptr, *sv0 = nullptr, *sv1 = nullptr;
+        void* s_tmp = nullptr;
+        size_t s_bytes = 0;
+        if (resort) {
+            const int ne = (int)a.n_emit;
+            const size_t a4 = ((size_t)ne * 4 + 255) & ~(size_t)255;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, s_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, ne, 0,
+                                                       rte::SURVIVOR_KEY_BITS, ctx->stream));
+            if ((rc = ctx->st_aux.reserve(4 * a4 + s_bytes + 256))) return rc;
+            char* w = (char*)ctx->st_aux.p;
+            sk0 = (uint32_t*)w; sk1 = (uint32_t*)(w + a4); sv0 = (uint32_t*)(w + 2 * a4); sv1 = (uint32_t*)(w + 3 * a4);
+            s_tmp = w + 4 * a4;
+        }
+        const uint32_t* from_order = nullptr;
         // one launch per bounce; a later bounce's grid is sized for all photons and the lanes beyond the survivors leave at once
         rte::PhotonState* lists[2] = {(rte::PhotonState*)ctx->rays.p, (rte::PhotonState*)ctx->gq.p};
         for (int b = 0; b <= bounce; b++) {
+            const bool key_next = resort && b < bounce;
+            if (key_next) HIP_TRY(hipMemsetAsync(sk0, 0xFF, (size_t)a.n_emit * 4, ctx->stream));
 #define RT_LAUNCH_EMIT(TRI, MODE)                                                                                                                       \
     if ((rc = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rte::emit_kernel<double, TRI, MODE>), g.lds))) return rc;                               \
     hipLaunchKernelGGL((rte::emit_kernel<double, TRI, MODE>), dim3((unsigned)((a.n_emit + g.threads - 1) / g.threads)), dim3(g.threads), g.lds, ctx->stream, \
                        ctx->v64, sd, a, b, (const rte::PhotonState*)lists[b & 1], lists[(b + 1) & 1], (rte::PhotonOut*)ctx->hits_a.p, cap_s,               \
-                       (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap, ctx->n_nodes, order)
+                       (rte::PhotonOut*)ctx->hits_b.p, cap_v, ctr, cap, ctx->n_nodes, order, from_order, key_next ? sk0 : nullptr, key_next ? sv0 : nullptr)
             if (tri_only) {
                 if (g.mode == rtk::TRAV_NODES) { RT_LAUNCH_EMIT(true, rtk::TRAV_NODES); }
                 else if (g.mode == rtk::TRAV_RETEST) { RT_LAUNCH_EMIT(true, rtk::TRAV_RETEST); }
@@ -717,6 +735,10 @@ int emit_batches(rt_context* ctx, int64_t n_emit, const double light_pos[3], uin
             }
 #undef RT_LAUNCH_EMIT
             HIP_TRY(hipGetLastError());
+            if (key_next) {
+                HIP_TRY(hipcub::DeviceRadixSort::SortPairs(s_tmp, s_bytes, sk0, sk1, sv0, sv1, (int)a.n_emit, 0, rte::SURVIVOR_KEY_BITS, ctx->stream));
+                from_order = sv1;
+            }
         }
         HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         rte::EmitCounters hc;

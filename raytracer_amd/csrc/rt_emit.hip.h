@@ -104,6 +104,34 @@ __global__ void emit_order_keys_kernel(EmitArgs a, uint32_t* __restrict__ keys, 
 }
 constexpr int EMIT_ORDER_KEY_BITS = 15;
 
+// Which photons share a wave at a later bounce (optional): the survivors of a bounce keyed by the direction they go on in
+// (cube face, 4 x 4 cells on it: 7 bits) and, within a direction, by where they start (5 + 5 + 5 bit Morton code in the
+// scene's box), so that a wave's rays run roughly side by side.  Valid keys stay below 2^22; the host pads the key array
+// with a larger value, and a stable sort leaves the survivors in front.
+constexpr int SURVIVOR_KEY_BITS = 23;
+template <class R>
+__device__ __forceinline__ uint32_t survivor_key(const R* lo, const R* hi, const D3& org, const D3& d)
+{
+    const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    uint32_t face;
+    double u, v, m;
+    if (ax >= ay && ax >= az) { face = d.x < 0 ? 1u : 0u; m = ax; u = d.y; v = d.z; }
+    else if (ay >= az) { face = d.y < 0 ? 3u : 2u; m = ay; u = d.x; v = d.z; }
+    else { face = d.z < 0 ? 5u : 4u; m = az; u = d.x; v = d.y; }
+    const uint32_t qu = (uint32_t)fmin(3.0, (u / m * 0.5 + 0.5) * 4.0), qv = (uint32_t)fmin(3.0, (v / m * 0.5 + 0.5) * 4.0);
+    const uint32_t dir_bin = face << 4 | qv << 2 | qu;                                       // < 96
+    const double p[3] = {org.x, org.y, org.z};
+    uint32_t q[3];
+    for (int i = 0; i < 3; i++) {
+        const double e = (double)hi[i] - (double)lo[i];
+        const double t = e > 0 ? (p[i] - (double)lo[i]) / e : 0.0;
+        q[i] = (uint32_t)fmin(31.0, fmax(0.0, t * 32.0));
+    }
+    uint32_t mort = 0;
+    for (int b = 0; b < 5; b++) mort |= ((q[0] >> b) & 1u) << (3 * b) | ((q[1] >> b) & 1u) << (3 * b + 1) | ((q[2] >> b) & 1u) << (3 * b + 2);
+    return dir_bin << 15 | mort;
+}
+
 // One bounce of every photon still walking (main.cpp:396-600), one photon per lane.  Bounce 0 starts the photons at the
 // light; a later bounce takes the survivors of the one before, compacted: walks end at very different lengths, and a wave
 // that carried its photons from the light to their ends ran with a sixth of its lanes on average.
@@ -111,7 +139,8 @@ template <class R, bool TRI_ONLY, int MODE>
 __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> sv, ShadeTables sd, EmitArgs a, int bounce, const PhotonState* __restrict__ from,
                                                              PhotonState* __restrict__ onward, PhotonOut* __restrict__ surf, unsigned long long cap_s,
                                                              PhotonOut* __restrict__ vol, unsigned long long cap_v, EmitCounters* ctr, int cap, int n_nodes,
-                                                             const uint32_t* __restrict__ order)
+                                                             const uint32_t* __restrict__ order, const uint32_t* __restrict__ from_order,
+                                                             uint32_t* __restrict__ next_keys, uint32_t* __restrict__ next_vals)
 {
     extern __shared__ __align__(16) unsigned char lds[];
     const size_t node_bytes = MODE == rtk::TRAV_NODES ? rtk::node_lds_bytes<R>((size_t)n_nodes) : 0;
@@ -129,7 +158,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> 
     double light[3] = {1.0, 1.0, 1.0};   // white_light, main.cpp:637,685
     uint32_t draws = 0;
     if (alive && bounce > 0) {
-        const PhotonState& ps = from[local];
+        const PhotonState& ps = from[from_order ? (long long)from_order[local] : local];      // (see survivor_key)
         org = D3{ps.org[0], ps.org[1], ps.org[2]}; dir = D3{ps.dir[0], ps.dir[1], ps.dir[2]};
         for (int i = 0; i < 3; i++) light[i] = ps.light[i];
         pn = ps.pn; draws = ps.draws;
@@ -287,7 +316,9 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void emit_kernel(rtf::SceneView<R> 
                 ps.dir[0] = dir.x; ps.dir[1] = dir.y; ps.dir[2] = dir.z;
                 for (int i = 0; i < 3; i++) ps.light[i] = light[i];
                 ps.pn = pn; ps.draws = rng.ctr; ps.pad = 0;
-                onward[base + rtq::prefix_rank(m)] = ps;
+                const unsigned long long at = base + rtq::prefix_rank(m);
+                onward[at] = ps;
+                if (next_keys) { next_keys[at] = survivor_key(sv.root_lo, sv.root_hi, org, dir); next_vals[at] = (uint32_t)at; }
             }
         }
     }

@@ -616,6 +616,13 @@ def test_gpu_emission_statistics(gpu_ctx, tag, rgbs, ior, monkeypatch):
     monkeypatch.delenv("RT_EMIT_UNORDERED")
     assert st_plain.secondary_rays == st.secondary_rays
     assert np.array_equal(s.photons_get(0), dev[0]) and np.array_equal(s.photons_get(1), dev[1])
+    # nor does re-ordering the survivors between bounces (a comparison switch: measured slower, the sorts cost more than they return)
+    s.photons_clear()
+    monkeypatch.setenv("RT_EMIT_RESORT", "1")
+    st_sorted = s.emit_photons_gpu(gpu_ctx, n, seed=5)
+    monkeypatch.delenv("RT_EMIT_RESORT")
+    assert st_sorted.secondary_rays == st.secondary_rays
+    assert np.array_equal(s.photons_get(0), dev[0]) and np.array_equal(s.photons_get(1), dev[1])
     assert st.secondary_rays >= n
     for which in (0, 1):
         nh, ph_, hh = _emission_summary(host[which])
