@@ -116,3 +116,39 @@ def test_photon_pairs_a_rounding_error_apart(gpu_ctx, water_photons):
         again, _ = gpu_ctx.knn_estimate(p, pos[perm], nrm[perm], col[perm])
         assert np.abs(again - want[perm]).max() < 1e-12 * scale
         assert np.abs(gpu_ctx.knn_estimate_grouped(p, pos, nrm, col) - got).max() < 1e-12 * scale
+
+
+def test_scheduling_of_the_group_kernel_does_not_change_results(gpu_ctx, water_photons, monkeypatch):
+    """Which wave takes a window, or a part of one, and in which order the windows are drawn is scheduling: a round is
+    computed from the window and the lanes waiting alone.  Windows of several patches (runs of 16 neighbours from different
+    walls) with parts handed from wave to wave, without, in queue order, with rounds of any size, and with short packed
+    lists (more repeated searches, more boxes too large): the same estimates to the last bits.  The earlier group form over
+    listed leaves adds in another order: float rounding apart."""
+    gpu_ctx.photons_upload(water_photons)
+    pos, nrm = _wall_queries(40)
+    n = len(pos) // 16 * 16
+    perm = np.random.default_rng(11).permutation(n // 16)
+    idx = (perm[:, None] * 16 + np.arange(16)[None, :]).ravel()          # runs of 16 neighbours, the runs shuffled
+    pos, nrm = pos[idx], nrm[idx]
+    col = np.random.default_rng(3).uniform(0.2, 1.0, pos.shape)
+    for k in (1000, 100):
+        p = rt.default_params(photon_num=60000, photon_use=k)
+        base = gpu_ctx.knn_estimate_grouped(p, pos, nrm, col)
+        want, _ = gpu_ctx.knn_estimate(p, pos, nrm, col)
+        scale = max(1.0, want.max())
+        assert want.max() > 0.05 and np.abs(base - want).max() < 1e-6 * scale
+        for env in ({"RT_GATHER_NO_PARTS": "1"}, {"RT_GATHER_QUEUE_ORDER": "1"}, {"RT_GATHER_PART_TAIL": "0"}, {"RT_GATHER_WAVES": "3"}):
+            for name, val in env.items():
+                monkeypatch.setenv(name, val)
+            got = gpu_ctx.knn_estimate_grouped(p, pos, nrm, col)
+            for name in env:
+                monkeypatch.delenv(name)
+            assert np.abs(got - base).max() < 1e-12 * scale, (k, env, np.abs(got - base).max())
+        # other groupings of the same requests: same sets, other sums
+        for env in ({"RT_GATHER_MIN_LANES": "1"}, {"RT_GATHER_PACK_CAP": "2048"}, {"RT_GATHER_ACT_REACH": "1.0"}, {"RT_GATHER_FORM": "tile"}):
+            for name, val in env.items():
+                monkeypatch.setenv(name, val)
+            got = gpu_ctx.knn_estimate_grouped(p, pos, nrm, col)
+            for name in env:
+                monkeypatch.delenv(name)
+            assert np.abs(got - want).max() < 1e-6 * scale, (k, env, np.abs(got - want).max())
