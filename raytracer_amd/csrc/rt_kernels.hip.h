@@ -495,8 +495,8 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
                 else if (a.shadow == 2 && sid >= 0) ids[px] = id | SHADOWED_BIT;      // folded form: one word per pixel
             }
 #ifdef RT_TILE_END_TIMES
-            // (measurement build: when the pixel's wave was done; RT_TILE_PHASES: cycles of the camera phase in the even
-            // columns, of the shadow phase in the odd ones)
+            // (measurement build: when the pixel's wave was done; with rt_render_params.part = -7, instead, the cycles of the
+            // wave's camera phase in the even columns and of its shadow phase in the odd ones)
             if (t_out) t_out[px] = a.part == -7 ? (double)((x & 1) ? clock64() - c_mid : c_mid - c_begin) : (double)wall_clock64();
 #endif
         }
