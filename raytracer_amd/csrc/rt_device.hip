@@ -806,11 +806,12 @@ int build_photon_map_dev(rt_context* ctx, int which, long long n, const double* 
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t at = off; off += align(bytes); return at; };
-    const size_t n_bounds = (size_t)(n / 32 + 2) * 3;
-    const size_t o_k0 = carve(n * 8), o_k1 = carve(n * 8), o_v0 = carve(n * 4), o_v1 = carve(n * 4), o_ax = carve(n), o_mn = carve(n_bounds * 4),
-                 o_mx = carve(n_bounds * 4);
-    size_t sort_bytes = 0;
+    // (bounds of the ranges of every level behind one another: level l starts at 3 (2^l - 1))
     const int levels = rtkd::levels_for(n);
+    const size_t n_bounds = ((size_t)3 << levels) + 3;
+    const size_t o_k0 = carve(n * 8), o_k1 = carve(n * 8), o_v0 = carve(n * 4), o_v1 = carve(n * 4), o_ax = carve(n), o_mn = carve(n_bounds * 4),
+                 o_mx = carve(n_bounds * 4), o_xyz = carve(n * 16);
+    size_t sort_bytes = 0;
     int key_bits = 33;
     while (key_bits < 64 && (n >> (key_bits - 32)) != 0) key_bits++;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (unsigned*)nullptr,
@@ -823,18 +824,20 @@ int build_photon_map_dev(rt_context* ctx, int which, long long n, const double* 
     auto* axis_at = (unsigned char*)(w + o_ax); auto* mins = (unsigned*)(w + o_mn); auto* maxs = (unsigned*)(w + o_mx);
     const int T = 256;
     const dim3 grid((unsigned)((n + T - 1) / T));
-    rtkd::Source src{d_rec, stride};
+    rtkd::Source src{d_rec, stride, (const float4*)(w + o_xyz)};
+    hipLaunchKernelGGL(rtkd::compact_kernel, grid, dim3(T), 0, ctx->stream, d_rec, stride, ni, (float4*)(w + o_xyz));
     hipLaunchKernelGGL(rtkd::iota_kernel, grid, dim3(T), 0, ctx->stream, ni, v0);
     HIP_TRY(hipMemsetAsync(axis_at, 0, (size_t)n, ctx->stream));
+    HIP_TRY(hipMemsetAsync(mins, 0xFF, (o_mx - o_mn) + n_bounds * 4, ctx->stream));      // both arrays, every level (they lie behind one another)
     for (int level = 0; level < levels; level++) {
-        const size_t used = std::min(n_bounds, (size_t)3 << level);
-        HIP_TRY(hipMemsetAsync(mins, 0xFF, used * 4, ctx->stream));
-        HIP_TRY(hipMemsetAsync(maxs, 0, used * 4, ctx->stream));
-        hipLaunchKernelGGL(rtkd::bounds_kernel, dim3((unsigned)((n + (long long)T * rtkd::RUN - 1) / ((long long)T * rtkd::RUN))), dim3(T), 0, ctx->stream, src, ni, level,
-                           (const unsigned*)v0, mins, maxs);
-        hipLaunchKernelGGL(rtkd::key_kernel, grid, dim3(T), 0, ctx->stream, src, ni, level, (const unsigned*)v0, (const unsigned*)mins, (const unsigned*)maxs, k0,
-                           axis_at);
-        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + o_tmp, sort_bytes, k0, k1, v0, v1, ni, 0, key_bits, ctx->stream));
+        const size_t at = (size_t)3 * (((size_t)1 << level) - 1);
+        const long long per_block = (long long)T * rtkd::run_of_level(level);
+        hipLaunchKernelGGL(rtkd::bounds_kernel, dim3((unsigned)((n + per_block - 1) / per_block)), dim3(T), 0, ctx->stream, src, ni, level,
+                           (const unsigned*)v0, mins + at, maxs + at);
+        hipLaunchKernelGGL(rtkd::key_kernel, grid, dim3(T), 0, ctx->stream, src, ni, level, (const unsigned*)v0, (const unsigned*)(mins + at),
+                           (const unsigned*)(maxs + at), k0, axis_at);
+        // (the key's high part is the segment's ordinal among the level's: level + 2 bits)
+        HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + o_tmp, sort_bytes, k0, k1, v0, v1, ni, 0, std::min(key_bits, rtkd::key_bits_of_level(level)), ctx->stream));
         std::swap(v0, v1);
     }
     hipLaunchKernelGGL(rtkd::emit_kernel, grid, dim3(T), 0, ctx->stream, src, ni, (const unsigned*)v0, (const unsigned char*)axis_at,
@@ -921,7 +924,10 @@ int rt_emit_photon_maps_dev(rt_context* ctx, int64_t n_emit, const double light_
             const int T = 256;
             const double* raw = (const double*)ctx->ph_raw[which].p;
             hipLaunchKernelGGL(rtkd::gather_keys_kernel, dim3((unsigned)((n + T - 1) / T)), dim3(T), 0, ctx->stream, ni, raw, 10, 9, k0, v0);
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + 2 * a8 + 2 * a4, sort_bytes, k0, k1, v0, v1, ni, 0, 64, ctx->stream));
+            // (keys are photon number x 64 + bounce x 8 + slot: the bits of the launch's photon numbers and six more)
+            int order_bits = 7;
+            while (order_bits < 64 && ((unsigned long long)n_emit >> (order_bits - 6)) != 0) order_bits++;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(w + 2 * a8 + 2 * a4, sort_bytes, k0, k1, v0, v1, ni, 0, order_bits, ctx->stream));
             hipLaunchKernelGGL(rtkd::permute_kernel, dim3((unsigned)((n * 9 + T - 1) / T)), dim3(T), 0, ctx->stream, ni, (const unsigned*)v1, raw, 10,
                                (double*)ctx->ph_src[which].p);
             HIP_TRY(hipGetLastError());
