@@ -5,10 +5,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
 #include <thread>
 #include <array>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
 
 #include "rt_math.h"
 
@@ -141,16 +146,39 @@ void parse_corner(const std::string& tok, int& v, int& vt, int& vn)
 }
 }  // namespace
 
-int Scene::load_obj(const char* path, const double* rgbs, float ior, float xo, float yo, float zo, int use_texture, int map)
+namespace {
+// What a mesh file says, statement by statement, in the file's order (a face may only name vertices that came before it,
+// and a truncated face ends the file: IO.h:75-119).  Parsed once per file: a scene of instanced meshes loads the same
+// file thousands of times with different offsets, and reading and splitting 45 KB of text was nearly all of each load.
+struct ObjStatement {
+    enum Kind : int { V, VN, VT, F, END } kind;
+    double a[3];              // V / VN: x y z (as read, before the instance's offset); VT: u v
+    int v[3], vt[3], vn[3];   // F: zero-based corners, -1 when absent
+};
+struct ParsedObj {
+    std::vector<ObjStatement> st;
+    long long size = -1, mtime_ns = -1;      // of the file when it was parsed
+};
+std::mutex g_obj_mu;
+std::map<std::string, std::shared_ptr<const ParsedObj>> g_obj_cache;
+
+std::shared_ptr<const ParsedObj> parse_obj(const char* path)
 {
+    struct stat sb;
+    if (stat(path, &sb) != 0) return nullptr;
+    const long long size = (long long)sb.st_size, mtime_ns = (long long)sb.st_mtim.tv_sec * 1000000000ll + sb.st_mtim.tv_nsec;
+    {
+        std::lock_guard<std::mutex> lock(g_obj_mu);
+        auto it = g_obj_cache.find(path);
+        if (it != g_obj_cache.end() && it->second->size == size && it->second->mtime_ns == mtime_ns) return it->second;
+    }
     FILE* fp = fopen(path, "rb");
-    if (!fp) return -1;                      // the reference returns false silently (IO.h:72-73)
+    if (!fp) return nullptr;
     std::string text;
     char buf[1 << 16];
     size_t got;
     while ((got = fread(buf, 1, sizeof buf, fp)) > 0) text.append(buf, got);
     fclose(fp);
-
     // whitespace-separated words, exactly like the reference's `input >> head` stream (IO.h:75-119):
     // comment text is just a run of unknown words
     std::vector<std::string> words;
@@ -164,25 +192,54 @@ int Scene::load_obj(const char* path, const double* rgbs, float ior, float xo, f
             i = j;
         }
     }
-    std::vector<std::array<double, 3>> points, normals;
-    std::vector<std::array<double, 2>> uvs;
+    auto parsed = std::make_shared<ParsedObj>();
+    parsed->size = size; parsed->mtime_ns = mtime_ns;
     auto num = [&](size_t k) { return k < words.size() ? strtod(words[k].c_str(), nullptr) : 0.0; };
     for (size_t w = 0; w < words.size(); w++) {
         const std::string& head = words[w];
-        if (head == "v") {
-            points.push_back({num(w + 1) + xo, num(w + 2) + yo, num(w + 3) + zo});
-            w += 3;
-        } else if (head == "vn") {
-            normals.push_back({num(w + 1), num(w + 2), num(w + 3)});
+        ObjStatement e{};
+        if (head == "v" || head == "vn") {
+            e.kind = head == "v" ? ObjStatement::V : ObjStatement::VN;
+            e.a[0] = num(w + 1); e.a[1] = num(w + 2); e.a[2] = num(w + 3);
             w += 3;
         } else if (head == "vt") {
-            uvs.push_back({num(w + 1), num(w + 2)});
+            e.kind = ObjStatement::VT;
+            e.a[0] = num(w + 1); e.a[1] = num(w + 2);
             w += 2;
         } else if (head == "f") {
-            if (w + 3 >= words.size()) break;   // truncated face at end of file
-            int v[3], vt[3], vn[3];
-            for (int k = 0; k < 3; k++) parse_corner(words[w + 1 + k], v[k], vt[k], vn[k]);
+            if (w + 3 >= words.size()) { e.kind = ObjStatement::END; parsed->st.push_back(e); break; }   // truncated face at end of file
+            e.kind = ObjStatement::F;
+            for (int k = 0; k < 3; k++) parse_corner(words[w + 1 + k], e.v[k], e.vt[k], e.vn[k]);
             w += 3;
+        } else {
+            continue;
+        }
+        parsed->st.push_back(e);
+    }
+    std::lock_guard<std::mutex> lock(g_obj_mu);
+    if (g_obj_cache.size() >= 64) g_obj_cache.clear();      // (a handful of meshes in any real use; never grows without bound)
+    g_obj_cache[path] = parsed;
+    return parsed;
+}
+}  // namespace
+
+int Scene::load_obj(const char* path, const double* rgbs, float ior, float xo, float yo, float zo, int use_texture, int map)
+{
+    const std::shared_ptr<const ParsedObj> parsed = parse_obj(path);
+    if (!parsed) return -1;                  // the reference returns false silently (IO.h:72-73)
+    std::vector<std::array<double, 3>> points, normals;
+    std::vector<std::array<double, 2>> uvs;
+    for (const ObjStatement& e : parsed->st) {
+        if (e.kind == ObjStatement::V) {
+            points.push_back({e.a[0] + xo, e.a[1] + yo, e.a[2] + zo});
+        } else if (e.kind == ObjStatement::VN) {
+            normals.push_back({e.a[0], e.a[1], e.a[2]});
+        } else if (e.kind == ObjStatement::VT) {
+            uvs.push_back({e.a[0], e.a[1]});
+        } else if (e.kind == ObjStatement::END) {
+            break;
+        } else {
+            const int *v = e.v, *vt = e.vt, *vn = e.vn;
             for (int k = 0; k < 3; k++)
                 if (v[k] < 0 || v[k] >= (int)points.size()) return -2;   // reference: vector::at throws
             // new Triangle(points[v0], points[v1], points[v2], ...) = ctor order (A, C, B), IO.h:103
