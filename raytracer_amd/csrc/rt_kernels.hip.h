@@ -132,6 +132,16 @@ __device__ __forceinline__ void test_prim(const rtf::Prim<R>& p, const R* o, con
     R t;
     if (TRI_ONLY) t = rtm::tri_intersect_staged<R>(p.a, p.e1, p.e2, o, d);
     else t = p.kind == rtf::PRIM_TRI ? rtm::tri_intersect_staged<R>(p.a, p.e1, p.e2, o, d) : rtm::prim_intersect<R>(p, o, d);
+#ifdef RT_TRI_TWICE
+    // (measurement build: the triangle test's arithmetic a second time on operands the compiler cannot see to be the same,
+    // its result kept alive -- what the kernel's time owes to that arithmetic is the difference to the plain build)
+    if (TRI_ONLY && sizeof(R) == 4) {
+        R o2[3] = {o[0], o[1], o[2]};
+        asm volatile("" : "+v"(o2[0]), "+v"(o2[1]), "+v"(o2[2]));
+        const R t2 = rtm::tri_intersect_staged<R>(p.a, p.e1, p.e2, o2, d);
+        if (t2 != t && t2 == t2 && t == t) hit = -3;
+    }
+#endif
     if (t >= R(0) && t < dist) { dist = t; hit = (int)p.id; }
 }
 
