@@ -546,6 +546,11 @@ __device__ __forceinline__ Aux6 aux_fetch(const float* aux, uint32_t at)
     const float __attribute__((address_space(1)))* ax = as_global(aux) + 6 * (size_t)at;
     return Aux6{ax[0], ax[1], ax[2], ax[3], ax[4], ax[5]};
 }
+// ONE_NORMAL: every lane that sums has the same surface normal (the requests of a window on one flat wall, which is
+// most windows of a scene whose diffuse surfaces are planes): |n . u| of a photon is then the same for all lanes, and the
+// lane that stages the photon forms it once -- same operands, same order, same value as every lane would get -- instead
+// of 64 lanes forming it each (a fifth of the pass's instructions).
+template <bool ONE_NORMAL>
 __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_pack, const float* __restrict__ aux, float qx, float qy, float qz, float t_k, bool some,
                                                      float nx, float ny, float nz)
 {
@@ -565,7 +570,12 @@ __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_p
     for (int s = 0; s < n_steps; s++) {
         s_stage_put(st, p.x, p.y, p.z, lane, n);
         {
-            sa[lane] = a.b0; sa[WAVE + lane] = a.b1; sa[2 * WAVE + lane] = a.b2; sa[3 * WAVE + lane] = a.b3; sa[4 * WAVE + lane] = a.b4; sa[5 * WAVE + lane] = a.b5;
+            sa[lane] = a.b0; sa[WAVE + lane] = a.b1; sa[2 * WAVE + lane] = a.b2;
+            if (ONE_NORMAL) {
+                sa[3 * WAVE + lane] = fabsf(nx * a.b3 + ny * a.b4 + nz * a.b5);      // (nx, ny, nz: the one normal, in every lane)
+            } else {
+                sa[3 * WAVE + lane] = a.b3; sa[4 * WAVE + lane] = a.b4; sa[5 * WAVE + lane] = a.b5;
+            }
             __builtin_amdgcn_wave_barrier();
         }
         const int n_now = __builtin_amdgcn_readfirstlane(n);
@@ -575,6 +585,9 @@ __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_p
         const float4 p2 = pack_step(pack, s + 2 < n_steps ? s + 2 : n_steps - 1, n_pack, lane, n2);
         struct Quad { Xyz4 c; float4 pr, pg, pb, ux, uy, uz; };
         auto quad_all = [&](int j) {
+            if (ONE_NORMAL)
+                return Quad{s_quad_load(st, j), *reinterpret_cast<const float4*>(sa + j), *reinterpret_cast<const float4*>(sa + WAVE + j), *reinterpret_cast<const float4*>(sa + 2 * WAVE + j),
+                            *reinterpret_cast<const float4*>(sa + 3 * WAVE + j), float4{0.f, 0.f, 0.f, 0.f}, float4{0.f, 0.f, 0.f, 0.f}};
             return Quad{s_quad_load(st, j), *reinterpret_cast<const float4*>(sa + j), *reinterpret_cast<const float4*>(sa + WAVE + j), *reinterpret_cast<const float4*>(sa + 2 * WAVE + j),
                         *reinterpret_cast<const float4*>(sa + 3 * WAVE + j), *reinterpret_cast<const float4*>(sa + 4 * WAVE + j), *reinterpret_cast<const float4*>(sa + 5 * WAVE + j)};
         };
@@ -589,11 +602,17 @@ __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_p
                 const f2 c2 = {tc.c2, tc.c2}, A = {tc.A, tc.A}, B = {tc.B, tc.B};
                 const f2 ea = c2 * d.a, eb = c2 * d.b;
                 const f2 wa = A + B * f2{__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)}, wb = A + B * f2{__builtin_amdgcn_exp2f(eb.x), __builtin_amdgcn_exp2f(eb.y)};
-                const f2 n_x = {nx, nx}, n_y = {ny, ny}, n_z = {nz, nz};
-                const f2 ca = n_x * f2{ux4.x, ux4.y} + n_y * f2{uy4.x, uy4.y} + n_z * f2{uz4.x, uz4.y};
-                const f2 cb = n_x * f2{ux4.z, ux4.w} + n_y * f2{uy4.z, uy4.w} + n_z * f2{uz4.z, uz4.w};
-                const float sc0 = in0 ? fabsf(ca.x) * wa.x : 0.f, sc1 = in1 ? fabsf(ca.y) * wa.y : 0.f;
-                const float sc2 = in2 ? fabsf(cb.x) * wb.x : 0.f, sc3 = in3 ? fabsf(cb.y) * wb.y : 0.f;
+                float t0, t1, t2, t3;      // |n . u| of the four photons
+                if (ONE_NORMAL) {
+                    t0 = ux4.x; t1 = ux4.y; t2 = ux4.z; t3 = ux4.w;      // (staged in the place of the direction's first component)
+                } else {
+                    const f2 n_x = {nx, nx}, n_y = {ny, ny}, n_z = {nz, nz};
+                    const f2 ca = n_x * f2{ux4.x, ux4.y} + n_y * f2{uy4.x, uy4.y} + n_z * f2{uz4.x, uz4.y};
+                    const f2 cb = n_x * f2{ux4.z, ux4.w} + n_y * f2{uy4.z, uy4.w} + n_z * f2{uz4.z, uz4.w};
+                    t0 = fabsf(ca.x); t1 = fabsf(ca.y); t2 = fabsf(cb.x); t3 = fabsf(cb.y);
+                }
+                const float sc0 = in0 ? t0 * wa.x : 0.f, sc1 = in1 ? t1 * wa.y : 0.f;
+                const float sc2 = in2 ? t2 * wb.x : 0.f, sc3 = in3 ? t3 * wb.y : 0.f;
                 const f2 sa2 = {sc0, sc1}, sb2 = {sc2, sc3};
                 const f2 r = f2{pr4.x, pr4.y} * sa2 + f2{pr4.z, pr4.w} * sb2, g = f2{pg4.x, pg4.y} * sa2 + f2{pg4.z, pg4.w} * sb2, b = f2{pb4.x, pb4.y} * sa2 + f2{pb4.z, pb4.w} * sb2;
                 s0 += (double)(r.x + r.y);                   // main.cpp:286 without the hit colour, which the caller multiplies in
@@ -961,7 +980,16 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
             if (PROF) pr[TP_RANK] += clock64() - t_rank;
             // ---- 3c. the estimate over the set (main.cpp:262-295)
             Sum3 sum;
-            TILE_PROF(TP_SUM, sum = stream_sum(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, (float)r.normal[0], (float)r.normal[1], (float)r.normal[2]));
+            {
+                const float nx = (float)r.normal[0], ny = (float)r.normal[1], nz = (float)r.normal[2];
+                const unsigned long long m_sum = __ballot(summed);
+                const int l0 = m_sum ? __builtin_ctzll(m_sum) : 0;
+                const float ax = bcast(nx, l0), ay = bcast(ny, l0), az = bcast(nz, l0);
+                if (m_sum && !__ballot(summed && (nx != ax || ny != ay || nz != az)))
+                    TILE_PROF(TP_SUM, sum = stream_sum<true>(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, ax, ay, az));
+                else
+                    TILE_PROF(TP_SUM, sum = stream_sum<false>(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, nx, ny, nz));
+            }
             if (summed) {
                 const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
                 double rgb[3] = {r.color[0] * sum.s0 * sc, r.color[1] * sum.s1 * sc, r.color[2] * sum.s2 * sc};
