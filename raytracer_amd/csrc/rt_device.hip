@@ -1687,26 +1687,29 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     int part_tail = 2;
     if (const char* e = getenv("RT_GATHER_PART_TAIL")) part_tail = std::max(0, atoi(e));
 
-    // Subsurface materials: the group kernel forms their surface estimates and leaves them in the requests' records for the
-    // per-request kernel, which therefore only runs after it (no launch alongside: a record being completed must not be read).
+    // Subsurface materials: the group kernel (packed form) answers their surface estimates and their volume terms; a request it
+    // cannot finish is left in its record with the surface estimate for the per-request kernel (the one alongside reads
+    // such records past its caches: fresh_record).
     const bool sss_scene = ctx->has_sss && !getenv("RT_SSS_PER_REQUEST");      // (the switch: comparison runs)
+    const int sss_mode = !sss_scene ? 0 : (getenv("RT_SSS_VOLUME_PER_REQUEST") ? 1 : 2);      // (the switch: the volume terms per request, as the earlier form has them)
     rtg::TileArgs ta{recs, cnt, shard_cap, next_window, d_redo, n_redo, windows_done, ((mode && mode[0] == 'q') || ctx->pm[0].n == 0) ? 1 : 0,      // (an empty surface map has no tree to walk)
-                     sss_scene ? 1 : 0, prof ? (unsigned long long*)ctx->st_aux.p : nullptr, span ? (unsigned long long*)ctx->st_aux.p : nullptr,
+                     sss_mode, prof ? (unsigned long long*)ctx->st_aux.p : nullptr, span ? (unsigned long long*)ctx->st_aux.p : nullptr,
                      packed ? d_cont : nullptr, cont_cap, part_tail, getenv("RT_GATHER_QUEUE_ORDER") ? 0 : 1, pack_cap};
     HIP_TRY(hipEventRecord(ctx->ev_fork, ctx->stream));      // (the queue and the counters are ready here)
-    if (packed && prof) hipLaunchKernelGGL(rtg::gather_stream_prof_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc, d_pack);
+    if (packed && prof) hipLaunchKernelGGL(rtg::gather_stream_prof_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], ta, gpt, d_acc, d_pack);
+    else if (packed && sss_scene) hipLaunchKernelGGL(rtg::gather_stream_sss_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ctx->pm[1], ta, gpt, d_acc, d_pack);
     else if (packed) hipLaunchKernelGGL(rtg::gather_stream_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc, d_pack);
     else hipLaunchKernelGGL(rtg::gather_tile_kernel, dim3(tile_waves), dim3(rtg::WAVE), 0, ctx->stream, ctx->pm[0], ta, gpt, d_acc);
     HIP_TRY(hipGetLastError());
     // The per-request kernel alongside, on the second stream.  Its waves stay only once every wave of the group kernel
     // has begun, so they never hold a place the group kernel waits for; six blocks per CU leave room for one of the
     // group kernel's in any case.
-    const bool alongside = !sss_scene && !getenv("RT_GATHER_NO_ALONGSIDE");      // (the switch: comparison runs)
+    const bool alongside = (!sss_scene || packed) && !getenv("RT_GATHER_NO_ALONGSIDE");      // (the switch: comparison runs; the earlier group form has no fence before its hand-overs)
     if (alongside) {
         HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         hipLaunchKernelGGL(rtg::gather_alongside_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->side, ctx->pm[0], ctx->pm[1], recs, d_redo,
                            (uint32_t)std::min<size_t>(redo_entries, 0xFFFFFFFFu), cnt, shard_cap, (const unsigned long long*)windows_done, (unsigned)tile_waves,
-                           next_gather, gp, d_acc);
+                           next_gather, gp, d_acc, sss_scene ? 1 : 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ctx->ev_join, ctx->side));
     }

@@ -880,9 +880,25 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
 // after that the list is final, and an entry still empty lies beyond its end.  A wave of this kernel stays only if
 // every wave of the group kernel has begun (windows_done[1] counts them), i.e. it is not holding a place one of those
 // still needs: the group kernel is launched first and fills the device, and these waves move in as its waves leave.
+// `fresh_records`: the group kernel completes records before it hands them over (the surface estimate of a subsurface
+// request), on whichever part of the device its wave runs; a record is then read word by word with read-modify-write
+// operations that change nothing -- served where the device's writes meet, not from a cache that may hold the line as
+// the shading pass left it -- after the entry that announces it (the writer orders the two with a fence).
+__device__ __forceinline__ GatherRec fresh_record(const GatherRec* rec)
+{
+    static_assert(sizeof(GatherRec) == 14 * sizeof(unsigned long long), "fourteen words");
+    const int lane = lane_id();
+    unsigned long long w = 0;
+    if (lane < 14) w = atomicAdd(reinterpret_cast<unsigned long long*>(const_cast<GatherRec*>(rec)) + lane, 0ull);
+    union { GatherRec r; unsigned long long u[14]; } x;
+#pragma unroll
+    for (int i = 0; i < 14; i++)
+        x.u[i] = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(w >> 32), i) << 32) | (unsigned)__builtin_amdgcn_readlane((int)(unsigned)w, i);
+    return x.r;
+}
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_alongside_kernel(PhotonMapView pm, PhotonMapView vm, const GatherRec* __restrict__ recs, uint32_t* list,
                                                       uint32_t list_cap, const rtq::Counts* cnt, unsigned long long shard_cap, const unsigned long long* windows_done,
-                                                      unsigned tile_waves, unsigned long long* next, GatherParams gp, double* __restrict__ acc)
+                                                      unsigned tile_waves, unsigned long long* next, GatherParams gp, double* __restrict__ acc, int fresh_records)
 {
     const int lane = lane_id();
     const unsigned long long n_windows = rtq::map_units(cnt, shard_cap, WAVE).total;
@@ -913,7 +929,12 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
         if (slot == REDO_EMPTY) break;
         __builtin_amdgcn_wave_barrier();
         if (lane == 0) list[q0] = REDO_EMPTY;
-        answer_request(pm, vm, recs[slot], gp, nb, nbv, acc);
+        if (fresh_records) {
+            const GatherRec r = fresh_record(recs + slot);
+            answer_request(pm, vm, r, gp, nb, nbv, acc);
+        } else {
+            answer_request(pm, vm, recs[slot], gp, nb, nbv, acc);
+        }
     }
 }
 

@@ -35,9 +35,11 @@ namespace rtg {
 
 constexpr int S_PACK_CAP = 8192;      // photons the packed list of a wave holds at most (16 bytes each); TileArgs::pack_cap is the size in use
 constexpr int S_ATTEMPTS = 7;         // guesses at the centre's radius per round before the round is handed on
+constexpr int S_ATTEMPTS_VOLUME = 4;  // the same in a volume phase of a subsurface window (whose wave has three more phases to see to)
 constexpr int S_FLIGHT = 8;           // 64-photon steps of a streaming loop whose loads are in flight together
 constexpr int CONT_SHARDS = 8;        // lists of window parts handed from wave to wave (TileArgs::cont)
 constexpr int S_LEVEL = 320;          // subtrees of one tree level a group's box may touch
+constexpr int S_SSS_TRIES = 8;        // rounds a window with subsurface requests may take, its surface and volume phases together
 constexpr int S_CELL = 512;           // photons in the tree cell whose density gives the first guess
 
 // Per-wave LDS of the kernel: 12.5 KB, so that twelve waves share a CU.  The per-lane tables of the passes lie over
@@ -306,7 +308,11 @@ __device__ __attribute__((noinline)) int pack_refilter(float4* pack, int n_pack,
 // S_CELL photons that holds the centre is a box whose photons -- points on a surface -- fill its bounding box, so their
 // number over the box's face area (its two largest extents) is the density there, and r_k ~ sqrt(k / (pi density)).
 // The guess only has to be close: what the walk then lists is counted, and a second walk corrects a bad one.
-__device__ __attribute__((noinline)) float centre_guess(PhotonMapView pm, float cx, float cy, float cz, int k)
+// (`volume`: the map of photons scattered inside a subsurface material.  Where they fill the cell's box the density is
+// their number over its volume and r_k ~ cbrt(3 k / (4 pi density)); where they lie in a thin layer under the lit surface,
+// as they do when the free path is short, the surface form holds.  The larger of the two: a guess too small costs a
+// second walk, one too large only a longer list for the filter to cut down.)
+__device__ __attribute__((noinline)) float centre_guess(PhotonMapView pm, float cx, float cy, float cz, int k, bool volume)
 {
     const int lane = lane_id();
     int lo = 0, hi = (int)pm.n;
@@ -335,6 +341,11 @@ __device__ __attribute__((noinline)) float centre_guess(PhotonMapView pm, float 
     const float ex = wave_max_f(xx) - wave_min_f(nx), ey = wave_max_f(xy) - wave_min_f(ny), ez = wave_max_f(xz) - wave_min_f(nz);
     const float e_max = fmaxf(ex, fmaxf(ey, ez)), e_min = fminf(ex, fminf(ey, ez)), e_mid = ex + ey + ez - e_max - e_min;
     const float area = e_max * e_mid;
+    if (volume) {
+        if (!(area > 0.f)) return 0.f;
+        const float vol = area * e_min;
+        return fmaxf(cbrtf(3.f * (float)k * vol / (4.f * 3.14159265f * (float)(hi - lo))), sqrtf((float)k * area / (3.14159265f * (float)(hi - lo))));
+    }
     if (!(area > 0.f)) return 0.f;
     return sqrtf((float)k * area / (3.14159265f * (float)(hi - lo)));
 }
@@ -626,13 +637,74 @@ __device__ __attribute__((noinline)) Sum3 stream_sum(const float4* pack, int n_p
     return Sum3{s0, s1, s2};
 }
 
+// The sums of a subsurface step (main.cpp:310-334, 346-373) over the photons with d2 <= t_k of the VOLUME map: the powers
+// added up, and the position of the set's farthest photon -- the one at the k-th distance itself; of several at exactly
+// that distance the first in the tree, as volume_step picks it -- from which the caller takes the step's normaliser.
+// (Only that photon's tree position is noted on the way -- its coordinates, kept at hand for every quad, would cost the loop
+// the registers its fetches run ahead in -- and its position is read from the map at the end.)
+struct VolSum { double s0, s1, s2; float fx, fy, fz; };
+__device__ __attribute__((noinline)) VolSum stream_sum_volume(const float4* pack, int n_pack, const float4* __restrict__ pos, const float* __restrict__ aux, float qx, float qy, float qz,
+                                                              float t_k, bool some)
+{
+    float* const st = g_S.stage;
+    float* const sa = g_S.stage + 3 * WAVE;      // power r[64] g[64] b[64], tree position[64]
+    const int lane = lane_id();
+    double s0 = 0, s1 = 0, s2 = 0;
+    uint32_t f_at = 0xFFFFFFFFu;
+    n_pack = __builtin_amdgcn_readfirstlane(n_pack);
+    const int n_steps = (n_pack + WAVE - 1) / WAVE;
+    if (n_steps == 0) return VolSum{0, 0, 0, 0.f, 0.f, 0.f};
+    const float lim = some ? t_k : -1.f;
+    int n = 0, n1 = 0, n2 = 0;
+    float4 p = pack_step(pack, 0, n_pack, lane, n);                                    // step s
+    float4 p1 = pack_step(pack, n_steps > 1 ? 1 : 0, n_pack, lane, n1);               // step s + 1
+    Aux6 a = aux_fetch(aux, __float_as_uint(p.w));                                     // records of step s
+    for (int s = 0; s < n_steps; s++) {
+        s_stage_put(st, p.x, p.y, p.z, lane, n);
+        sa[lane] = a.b0; sa[WAVE + lane] = a.b1; sa[2 * WAVE + lane] = a.b2; sa[3 * WAVE + lane] = p.w;
+        __builtin_amdgcn_wave_barrier();
+        const int n_now = __builtin_amdgcn_readfirstlane(n);
+        a = aux_fetch(aux, __float_as_uint(p1.w));
+        const float4 p2 = pack_step(pack, s + 2 < n_steps ? s + 2 : n_steps - 1, n_pack, lane, n2);
+        struct Quad { Xyz4 c; float4 pr, pg, pb, at; };
+        auto quad_all = [&](int j) {
+            return Quad{s_quad_load(st, j), *reinterpret_cast<const float4*>(sa + j), *reinterpret_cast<const float4*>(sa + WAVE + j), *reinterpret_cast<const float4*>(sa + 2 * WAVE + j),
+                        *reinterpret_cast<const float4*>(sa + 3 * WAVE + j)};
+        };
+        for_quads(n_now, quad_all, [&](const Quad& q) {
+            const D2x4 d = quad_d2(q.c, qx, qy, qz);
+            // (as in stream_sum: a photon outside the lane's ball contributes a factor 0; four terms of a channel are added in float)
+            const f2 sa2 = {d.a.x <= lim ? 1.f : 0.f, d.a.y <= lim ? 1.f : 0.f}, sb2 = {d.b.x <= lim ? 1.f : 0.f, d.b.y <= lim ? 1.f : 0.f};
+            const f2 r = f2{q.pr.x, q.pr.y} * sa2 + f2{q.pr.z, q.pr.w} * sb2, g = f2{q.pg.x, q.pg.y} * sa2 + f2{q.pg.z, q.pg.w} * sb2, b = f2{q.pb.x, q.pb.y} * sa2 + f2{q.pb.z, q.pb.w} * sb2;
+            s0 += (double)(r.x + r.y);                   // main.cpp:329, 368 without the hit colour and the 0.2, which the caller multiplies in
+            s1 += (double)(g.x + g.y);
+            s2 += (double)(b.x + b.y);
+            // the photon at the k-th distance (no branch around this, rare as it is: with one the compiler splits the step in
+            // two and parks what the next quad has read ahead in scratch memory, whose reads wait for the fetches in flight)
+            const uint32_t none = 0xFFFFFFFFu;
+            f_at = min(f_at, min(min(d.a.x == lim ? __float_as_uint(q.at.x) : none, d.a.y == lim ? __float_as_uint(q.at.y) : none),
+                                 min(d.b.x == lim ? __float_as_uint(q.at.z) : none, d.b.y == lim ? __float_as_uint(q.at.w) : none)));
+        });
+        p = p1; n = n1;
+        p1 = p2; n1 = n2;
+    }
+    const float4 f = load_global4(pos + (f_at != 0xFFFFFFFFu ? f_at : 0u));
+    return VolSum{s0, s1, s2, f.x, f.y, f.z};
+}
+
 // Slots of the cycle accounting that mean something else here than in gather_tile_kernel: TP_KTH = walk + packing + the
 // centre's radix passes of all attempts, TP_WALK = the in-place filter, TP_N_HIST = attempts, TP_N_CRIT = photons packed
 // by the last attempt, TP_N_SUM = photons streamed by the passes.
 // PROF: the instantiation with the cycle accounting (its counters take some ninety registers), launched only when
 // TileArgs::prof is given.
-template <bool PROF>
-__device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, const TileArgs& ta, const GatherParams& gp, double* __restrict__ acc, float4* pack_all)
+// SSS: the instantiation that also answers the VOLUME terms of subsurface requests (the three findKNN calls in the map of
+// photons scattered inside the material, main.cpp:310, 346): after a window's rounds over the surface map its subsurface
+// requests go through up to three more phases of rounds over the volume map `vm` -- at the hit point, 0.02 along the
+// refracted direction, and one random step further -- with the same machinery; a request whose every phase succeeded is
+// finished here (surface + volume terms, clipped, main.cpp:389-391), any other is handed on with its surface estimate.
+// The state of a request between its phases is in its lane's registers, so such windows are not split into parts.
+template <bool PROF, bool SSS>
+__device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, const PhotonMapView& vm, const TileArgs& ta, const GatherParams& gp, double* __restrict__ acc, float4* pack_all)
 {
     uint32_t* const cell = g_S.table;
     const int lane = lane_id();
@@ -645,6 +717,11 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
         const uint32_t units = lane < rtq::SHARDS ? (map.n + WAVE - 1) / WAVE : 0u;
         n_draws = (uint32_t)wave_max_f((float)units) * rtq::SHARDS;      // (window counts are far below 2^24: exact in float)
     }
+    // With volume terms to answer, the windows are gone through twice: first those that hold subsurface requests -- four
+    // phases of rounds each, several times the work of any other window, and a wave that drew one near the end would set the
+    // kernel's length -- then the rest.  A look at a window's flags tells which kind it is (a few microseconds per window skipped).
+    const bool two_sweeps = SSS && ta.sss_surface > 1;
+    const uint32_t n_all = two_sweeps ? 2u * n_draws : n_draws;
     if (lane == 0) atomicAdd(ta.windows_done + 1, 1ull);
     const unsigned long long span_begin = ta.span ? wall_clock64() : 0ull;
     unsigned span_windows = 0, span_spins = 0;
@@ -657,6 +734,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
     const unsigned long long t_begin = PROF ? clock64() : 0ull;
     const float r_max = sqrtf(gp.r2);
     float prev_r = -1.f;                 // the last centre's k-th distance: the next guess
+    float prev_r_vol = -1.f;             // (the same in the volume map)
 #define TILE_PROF(slot, expr) do { if (PROF) { const unsigned long long t_ = clock64(); expr; pr[slot] += clock64() - t_; } else { expr; } } while (0)
 #define TILE_COUNT(slot, cond) do { if (PROF) pr[slot] += __builtin_popcountll(__ballot(cond)); } while (0)
     while (true) {
@@ -684,16 +762,19 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
         const bool part = c_word != 0;                // a handed-on part: its window, the lanes waiting, the rounds the window has had
         const int round_first = part ? (int)((c_word >> 32) & 0xFFu) : 0;
         uint32_t win;
+        bool first_sweep = false;
         if (part) {
             win = (uint32_t)c_word;
             sharing = true;
         } else {
             unsigned long long w0 = 0;
             if (lane == 0) w0 = atomicAdd(ta.next, 1ull);
-            const uint32_t drawn = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)w0);
+            uint32_t drawn = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)w0);
             const uint32_t drawn_hi = (uint32_t)__builtin_amdgcn_readfirstlane((unsigned)(w0 >> 32));
-            if (drawn_hi || drawn >= n_draws) break;     // (the high half is zero for any real queue); parts handed on later stay with their wave
-            sharing = ta.cont != nullptr && (unsigned long long)drawn + (unsigned long long)ta.part_tail * gridDim.x >= n_draws;
+            if (drawn_hi || drawn >= n_all) break;       // (the high half is zero for any real queue); parts handed on later stay with their wave
+            sharing = ta.cont != nullptr && (unsigned long long)drawn + (unsigned long long)ta.part_tail * gridDim.x >= n_all;
+            first_sweep = two_sweeps && drawn < n_draws;
+            if (two_sweeps && !first_sweep) drawn -= n_draws;
             if (ta.late_first) {
                 // The shards' windows from the last appended to the first, the shards taken in turn: what the later shading
                 // passes queued -- hit points of rays that left a refracting or reflecting surface, scattered where a tile of
@@ -708,7 +789,6 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                 win = drawn;
             }
         }
-        span_windows++;
         unsigned shard;
         uint32_t first, n_shard;
         rtq::locate(map, win, WAVE, shard, first, n_shard);
@@ -716,12 +796,17 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
         const int n_req = (int)((ta.recs[slot0].flags >> GATHER_COUNT_SHIFT) & 127u);
         const bool have = lane < n_req;
         const GatherRec& r = ta.recs[slot0 + (have ? lane : 0)];
-        const float qx = (float)r.pos[0], qy = (float)r.pos[1], qz = (float)r.pos[2];
+        float qx = (float)r.pos[0], qy = (float)r.pos[1], qz = (float)r.pos[2];
+        const float hx = qx, hy = qy, hz = qz;      // the hit point (a volume phase asks elsewhere)
         const uint32_t flags = r.flags & 0xFFu;
         // Subsurface requests: their surface estimate is one of four gathers (main.cpp:260-388) and the only one in this
-        // map; it is formed here with the group's, written into the record, and the request handed on for the rest.
+        // map; it is formed here with the group's.  The subsurface instantiation answers the other three as well; otherwise,
+        // and where it cannot, the estimate is written into the record and the request handed on for the rest.
         const bool sss = (flags & GATHER_SSS) != 0;
-        bool redo = have && ((flags & ~(GATHER_SSS | GATHER_MARCH)) != 0 || (sss && !ta.sss_surface) || ta.all_redo || pm.n >= (1ll << 24));
+        const bool keep_whole = SSS && __ballot(have && sss) != 0;      // (a window with subsurface requests stays with this wave: see the phases)
+        if (two_sweeps && !part && keep_whole != first_sweep) continue;      // (the other sweep's)
+        span_windows++;
+        bool redo = have && ((flags & ~(GATHER_SSS | GATHER_MARCH)) != 0 || (sss && (!SSS || !ta.sss_surface)) || ta.all_redo || pm.n >= (1ll << 24));      // (subsurface requests: the subsurface instantiation's)
         bool todo = have && !redo;
         if (part) { redo = false; todo = have && ((c_mask >> lane) & 1ull) != 0; }      // (the parts before this one saw to the other lanes)
         if (PROF) pr[TP_WINDOWS]++;
@@ -735,7 +820,35 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
         // (the fewest requests worth a round: measured on the water frame with windows taken late-first and parts handed on --
         // k = 1000: 1 / 2 / 4 / 6 / 8 / 12 requests give 8.3 / 8.1 / 8.0 / 7.4 / 7.5 / 7.6 ms; k = 100: 1 / 2 / 4 / 6 / 8 give 4.7 / 4.8 / 4.9 / 5.0 / 5.1)
         const int MIN_LANES = gp.min_lanes > 0 ? gp.min_lanes : (gp.k >= 400 ? 6 : 1);
-        for (int round = round_first; round < ROUNDS; round++) {
+        // subsurface requests between their phases: the surface estimate is formed (sss_wait), the volume terms so far
+        const bool volume_here = SSS && ta.sss_surface > 1;
+        bool sss_wait = false;
+        int tries = 0;      // rounds begun, all phases together
+        float vol_r_here = -1.f, vol_cx = 0.f, vol_cy = 0.f, vol_cz = 0.f;      // the last volume round of this window: its centre and k-th distance
+        double surf0 = 0, surf1 = 0, surf2 = 0, vol0 = 0, vol1 = 0, vol2 = 0;
+        for (int phase = 0; phase < (SSS ? 4 : 1); phase++) {
+        const bool volume = SSS && phase > 0;
+        double e_pass = 1.0;                        // e^pass of main.cpp:371
+        if (volume) {
+            // phase 1: around the hit point (main.cpp:310); 2 and 3: the march of main.cpp:337-376, where refraction is possible
+            const bool in_phase = volume_here && sss_wait && !redo && vm.n > 0 && vm.n < (1ll << 24) && (phase == 1 || (flags & GATHER_MARCH) != 0);
+            if (!__ballot(in_phase)) break;
+            todo = in_phase;
+            if (phase >= 2) {
+                double px = r.pos[0] + r.march[0] * 0.02, py = r.pos[1] + r.march[1] * 0.02, pz = r.pos[2] + r.march[2] * 0.02;      // main.cpp:341
+                e_pass = 2.71828;
+                if (phase == 3) {
+                    // (the step length as answer_request draws it: keyed by pixel, hit point and pass)
+                    const uint32_t where = __float_as_uint(hx) * 0x9E3779B1u ^ __float_as_uint(hy) * 0x85EBCA77u ^ __float_as_uint(hz) * 0xC2B2AE3Du;
+                    const double d = -log(unit_random(r.pixel, where + 1u, gp.seed)) / 200;      // main.cpp:374
+                    px += r.march[0] * d; py += r.march[1] * d; pz += r.march[2] * d;
+                    e_pass *= 2.71828;
+                }
+                qx = (float)px; qy = (float)py; qz = (float)pz;
+            }
+        }
+        const PhotonMapView& map = volume ? vm : pm;
+        for (int round = (phase == 0 ? round_first : 0); round < ROUNDS; round++) {
             const unsigned long long m_todo = __ballot(todo);
             if (!m_todo) break;
             // ---- the round's centre: the middle one of the requests waiting
@@ -758,6 +871,15 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                 todo = todo && !near;
                 continue;
             }
+            // A window of subsurface requests is one wave's from its first phase to its last, and the longest such window is the
+            // least the kernel takes: past S_SSS_TRIES rounds (four phases of one round each is the common case, of two across a
+            // silhouette) what still waits goes to the per-request kernel.
+            if (keep_whole && ++tries > S_SSS_TRIES) {
+                TILE_COUNT(TP_R_LEFT, todo);
+                redo = redo || todo;
+                todo = false;
+                break;
+            }
             // ---- 1. the centre's k-th distance r_c (< 0: fewer than k photons within the search radius)
             float r_c = -1.f, R_found = 0.f;
             int n_pack = 0;
@@ -767,10 +889,17 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                 // The guess only has to be within a factor of a few: the photons actually counted inside it correct it
                 // (density ~ count / R^2 on a surface), so a second walk, where one is needed, starts from a good radius.
                 float guess;
-                TILE_PROF(TP_C_GUESS, guess = centre_guess(pm, cx, cy, cz, gp.k) * 1.15f);
-                if (!(guess > 0.f)) { guess = prev_r > 0.f ? prev_r * 1.2f : r_max * 0.3f; if (PROF) pr[TP_A_NOGUESS]++; }
+                if (volume && phase >= 2 && vol_r_here > 0.f) {
+                    // (the march moves the centre a few hundredths: the radius found a phase ago, and what the move can add)
+                    const float mx = cx - vol_cx, my = cy - vol_cy, mz = cz - vol_cz;
+                    guess = (vol_r_here + sqrtf(mx * mx + my * my + mz * mz)) * 1.02f;
+                } else {
+                    TILE_PROF(TP_C_GUESS, guess = centre_guess(map, cx, cy, cz, gp.k, volume) * 1.15f);
+                }
+                const float prev = volume ? prev_r_vol : prev_r;
+                if (!(guess > 0.f)) { guess = prev > 0.f ? prev * 1.2f : r_max * 0.3f; if (PROF) pr[TP_A_NOGUESS]++; }
                 float too_small = 0.f, too_large = 3.0e38f;      // radii that held fewer than k photons / overflowed the lists
-                for (int attempt = 0; attempt < S_ATTEMPTS && !found; attempt++) {
+                for (int attempt = 0; attempt < (volume ? S_ATTEMPTS_VOLUME : S_ATTEMPTS) && !found; attempt++) {
                     if (PROF) pr[TP_N_HIST]++;
                     const float R = fminf(guess, r_max);
                     const bool whole = !(R < r_max);                            // the search radius itself: nothing larger to try
@@ -783,24 +912,25 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                     const float reach = wave_max_f(cand ? d_c : 0.f) + rad;
                     __builtin_amdgcn_wave_barrier();
                     int lists;
-                    TILE_PROF(TP_C_WALK, lists = stream_walk(pm, glx, gly, glz, ghx, ghy, ghz));
+                    TILE_PROF(TP_C_WALK, lists = stream_walk(map, glx, gly, glz, ghx, ghy, ghz));
                     if (lists < 0) {
                         if (PROF) pr[TP_A_LISTS]++;
                         // too much of the tree: a smaller radius, unless that is known to hold fewer than k photons
                         too_large = fminf(too_large, R);
-                        guess = fmaxf(R * 0.6f, sqrtf(too_small * R));
+                        // (the photons in reach go with the radius squared on a surface, cubed in a volume: a smaller step back there)
+                        guess = fmaxf(R * (volume ? 0.8f : 0.6f), sqrtf(too_small * R));
                         if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
                         continue;
                     }
                     const int n_leaf = lists & 0xFFFF, n_piv = lists >> 16;
                     const float lim = whole ? gp.r2 : R * R;
                     int packed, inside = 0;
-                    TILE_PROF(TP_C_PACK, packed = pack_listed(pm.pos, pack, ta.pack_cap, cx, cy, cz, reach * reach * 1.0001f, lim, n_leaf, n_piv, &inside));
+                    TILE_PROF(TP_C_PACK, packed = pack_listed(map.pos, pack, ta.pack_cap, cx, cy, cz, reach * reach * 1.0001f, lim, n_leaf, n_piv, &inside));
                     __builtin_amdgcn_wave_barrier();
                     if (packed < 0) {
                         if (PROF) pr[TP_A_PACK]++;
                         too_large = fminf(too_large, R);
-                        guess = fmaxf(R * 0.7f, sqrtf(too_small * R));
+                        guess = fmaxf(R * (volume ? 0.85f : 0.7f), sqrtf(too_small * R));
                         if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
                         continue;
                     }
@@ -808,7 +938,8 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                         // too few: the radius that would hold k at the density just counted, and a margin
                         if (PROF) pr[TP_A_FEW]++;
                         too_small = fmaxf(too_small, R);
-                        const float grow = sqrtf((float)gp.k / (float)(inside > 0 ? inside : 1)) * 1.15f;
+                        const float ratio = (float)gp.k / (float)(inside > 0 ? inside : 1);
+                        const float grow = (volume ? cbrtf(ratio) : sqrtf(ratio)) * 1.15f;      // (the count grows with the radius squared on a surface, cubed in a volume)
                         guess = fminf(R * fminf(grow, 3.f), too_large < 3.0e38f ? sqrtf(R * too_large) : 3.0e38f);
                         if (guess >= too_large * 0.98f || guess <= R * 1.02f) break;
                         continue;
@@ -839,7 +970,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
             bool act = near;
             float bound = gp.r2, lower = 0.f;
             if (r_c >= 0.f) {
-                prev_r = r_c;
+                if (volume) { prev_r_vol = r_c; vol_r_here = r_c; vol_cx = cx; vol_cy = cy; vol_cz = cz; } else prev_r = r_c;
                 // this round: the requests inside the centre's own ball and a little beyond, as far as the packed list reaches
                 act = todo && d_c <= fminf(r_c * gp.act_reach, R_found);
                 // r_k(q) lies within |q - q_c| of r_c (triangle inequality).  For a request far from the centre that
@@ -871,7 +1002,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
             // window and the lanes waiting alone, so the results do not depend on who takes the part.
             {
                 const unsigned long long m_left = __ballot(todo);
-                if (sharing && m_left && round + 1 < ROUNDS) {
+                if (sharing && m_left && round + 1 < ROUNDS && !keep_whole) {
                     unsigned long long at = ~0ull;
                     if (lane == 0) {
                         at = atomicAdd(my_cont + 2, 1ull);
@@ -978,6 +1109,20 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
             const bool summed = some && !split_tie;
             __builtin_amdgcn_wave_barrier();
             if (PROF) pr[TP_RANK] += clock64() - t_rank;
+            // ---- 3c. a volume phase: the step's sums over the set (main.cpp:310-334, 346-373)
+            if (volume) {
+                VolSum vs;
+                TILE_PROF(TP_SUM, vs = stream_sum_volume(pack, n_pack, map.pos, map.aux, qx, qy, qz, t_k, summed));
+                if (summed) {
+                    // normalised by the distance from the HIT POINT to the farthest photon of the set (main.cpp:317, 353)
+                    const float dx = hx - vs.fx, dy = hy - vs.fy, dz = hz - vs.fz;
+                    const float m = dx * dx + dy * dy + dz * dz;
+                    const double scale = 1.0 / (e_pass * gp.photon_num / 8 * 3.1415926 * m * sqrtf(m));      // main.cpp:332, 371
+                    vol0 += (r.color[0] * vs.s0) * 0.2 * scale; vol1 += (r.color[1] * vs.s1) * 0.2 * scale; vol2 += (r.color[2] * vs.s2) * 0.2 * scale;
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
             // ---- 3c. the estimate over the set (main.cpp:262-295)
             Sum3 sum;
             {
@@ -993,20 +1138,36 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
             if (summed) {
                 const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
                 double rgb[3] = {r.color[0] * sum.s0 * sc, r.color[1] * sum.s1 * sc, r.color[2] * sum.s2 * sc};
-                if (sss) {
-                    GatherRec* const w = const_cast<GatherRec*>(&r);
-                    w->normal[0] = rgb[0]; w->normal[1] = rgb[1]; w->normal[2] = rgb[2];
-                    w->flags = r.flags | GATHER_SURFACE_DONE;
-                    redo = true;
+                if (SSS && sss) {
+                    surf0 = rgb[0]; surf1 = rgb[1]; surf2 = rgb[2];
                 } else {
                     clip3(rgb);                                    // main.cpp:391
                     for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
                 }
             }
+            // (a subsurface request with no surface photon in reach has a surface estimate, too: zero)
+            if (SSS && sss && act && !split_tie) sss_wait = true;
             __builtin_amdgcn_wave_barrier();
         }
         TILE_COUNT(TP_R_LEFT, todo);
         redo = redo || todo;
+        todo = false;
+        }      // (phases)
+        if (SSS && sss_wait) {
+            if (volume_here && !redo) {
+                // every phase answered: surface + volume terms (main.cpp:389), clipped (main.cpp:391)
+                double rgb[3] = {surf0 + vol0, surf1 + vol1, surf2 + vol2};
+                clip3(rgb);
+                for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
+            } else {
+                // handed on with the surface estimate: the per-request kernel adds the volume terms
+                GatherRec* const w = const_cast<GatherRec*>(&r);
+                w->normal[0] = surf0; w->normal[1] = surf1; w->normal[2] = surf2;
+                w->flags = r.flags | GATHER_SURFACE_DONE;
+                redo = true;
+            }
+        }
+        if (SSS && __ballot(sss_wait)) __threadfence();      // (a completed record is visible before the entry that hands it over: the kernel alongside reads it at once)
         if (PROF) {
             const unsigned long long dt = clock64() - t_window;
             if (rounds_done <= 1) { pr[TP_W_ROUNDS1]++; pr[TP_W_CYC1] += dt; }
@@ -1050,13 +1211,19 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
 __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void gather_stream_kernel(PhotonMapView pm, TileArgs ta, GatherParams gp, double* __restrict__ acc,
                                                                                                          float4* pack_all)
 {
-    gather_stream_body<false>(pm, ta, gp, acc, pack_all);
+    gather_stream_body<false, false>(pm, pm, ta, gp, acc, pack_all);
+}
+// the same with the volume terms of subsurface requests (see gather_stream_body): launched for scenes that have such materials
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(3, 3))) void gather_stream_sss_kernel(PhotonMapView pm, PhotonMapView vm, TileArgs ta, GatherParams gp,
+                                                                                                             double* __restrict__ acc, float4* pack_all)
+{
+    gather_stream_body<false, true>(pm, vm, ta, gp, acc, pack_all);
 }
 // (the accounting's registers would spill at three waves per SIMD and distort what it measures)
-__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_stream_prof_kernel(PhotonMapView pm, TileArgs ta, GatherParams gp, double* __restrict__ acc,
-                                                                                                              float4* pack_all)
+__global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) void gather_stream_prof_kernel(PhotonMapView pm, PhotonMapView vm, TileArgs ta, GatherParams gp,
+                                                                                                              double* __restrict__ acc, float4* pack_all)
 {
-    gather_stream_body<true>(pm, ta, gp, acc, pack_all);
+    gather_stream_body<true, true>(pm, vm, ta, gp, acc, pack_all);
 }
 
 }  // namespace rtg

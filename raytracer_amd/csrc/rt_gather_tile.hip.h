@@ -78,7 +78,8 @@ struct TileArgs {
     unsigned long long* windows_done;   // [0] windows finished, their hand-overs written; [1] waves of this kernel that have begun (the per-query kernel that runs alongside goes by both)
     int all_redo;                    // nonzero: hand every request to the per-query kernel (comparison runs)
     int sss_surface;                 // nonzero: form the surface estimate of subsurface requests here and hand the rest on (the per-request
-                                     // kernel must then run AFTER this one: the result travels in the request's record)
+                                     // kernel must then run AFTER this one: the result travels in the request's record); 2: the packed
+                                     // form's subsurface instantiation answers their volume terms as well and hands on what it cannot finish
     unsigned long long* prof;        // optional cycle accounting (development aid): TP_* slots
     unsigned long long* span;        // optional (development aid): per wave of the packed form, when it began and ended (100 MHz clock) and the windows it took
     // The packed form's lists of window parts handed from wave to wave (see gather_stream_body), CONT_SHARDS of them, each:

@@ -299,9 +299,12 @@ def test_render_subsurface(gpu_ctx):
     assert within >= 0.99 and rmse <= 1.0
 
 
-def test_subsurface_surface_term_in_groups_equals_per_request(gpu_ctx, monkeypatch):
-    """The group gather forms the surface estimate of subsurface requests and hands them on for their volume terms; with
-    every gather answered per request the frame is the same to the rounding of the float partial sums."""
+def test_subsurface_terms_in_groups_equal_per_request(gpu_ctx, monkeypatch):
+    """The group gather answers the surface estimate of subsurface requests and their three volume terms (main.cpp:310,
+    346: at the hit point and along the march) and finishes the request; what it cannot take it hands on with the surface
+    estimate in the record.  With every gather answered per request the frame is the same to the rounding of the float
+    partial sums -- also with the volume terms alone per request, and with the per-request kernel only after the group
+    kernel instead of alongside it (the hand-over of completed records)."""
     g = golden("render_sss_64.npz")
     s = build_scene(rt.Scene(), "teapot_normal.obj", tuple(g["rgbs"]), float(g["ior"]), (0, -0.7, 0))
     s.emit_photons(20000, seed=12345)
@@ -319,9 +322,45 @@ def test_subsurface_surface_term_in_groups_equals_per_request(gpu_ctx, monkeypat
             assert st_g.gather_queries == st_q.gather_queries > 5000
             assert grouped.max() > 0.05
             err = np.abs(grouped - single).max()
-            print(f"subsurface, grouped surface term vs per request (head_quirk {quirk}): max abs difference {err:.3e}, {st_g.gather_single} of {st_g.gather_queries} requests one per wave")
+            print(f"subsurface, grouped terms vs per request (head_quirk {quirk}): max abs difference {err:.3e}, {st_g.gather_single} of {st_g.gather_queries} requests one per wave")
             assert err < 2e-6 * max(1.0, np.abs(single).max())
+            for switch in ("RT_SSS_VOLUME_PER_REQUEST", "RT_GATHER_NO_ALONGSIDE"):
+                monkeypatch.setenv(switch, "1")
+                other, _, st_o = gpu_ctx.render(cam, p)
+                monkeypatch.delenv(switch)
+                err = np.abs(other - single).max()
+                print(f"  {switch}: max abs difference {err:.3e}, {st_o.gather_single} one per wave")
+                assert err < 2e-6 * max(1.0, np.abs(single).max())
+                if switch == "RT_SSS_VOLUME_PER_REQUEST":      # (every subsurface request ends per request then; the groups finish many of them)
+                    assert st_o.gather_single > 2 * st_g.gather_single
     finally:
+        gpu_ctx.photons_upload(np.zeros((0, 9)), which=1)
+
+
+def test_subsurface_full_frame_volume_terms_in_groups(gpu_ctx, monkeypatch):
+    """The subsurface teapot at 1920x1080 with maps of 200 000 emitted photons and k = 1000: the frame with the volume terms
+    answered in groups against the one with them answered per request (surface estimates in groups in both), every pixel."""
+    s = rt.Scene()
+    s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.9, 0.7, 0.6, -1.0), 1.3, (0, -0.7, 0))
+    s.add_cornell()
+    s.build_bvh()
+    gpu_ctx.upload(s)
+    (ns, nv), _ = gpu_ctx.emit_photon_maps(200000, seed=12345)
+    assert ns > 100000 and nv > 20000
+    try:
+        cam = rt.look_at((2.8, 0, 0), (0, 0, 0))
+        p = rt.default_params(width=1920, height=1080, photon_num=200000, photon_use=1000)
+        grouped, _, st_g = gpu_ctx.render(cam, p)
+        monkeypatch.setenv("RT_SSS_VOLUME_PER_REQUEST", "1")
+        single, _, st_q = gpu_ctx.render(cam, p)
+        monkeypatch.delenv("RT_SSS_VOLUME_PER_REQUEST")
+        err = np.abs(grouped - single).max()
+        print(f"subsurface 1920x1080 k=1000: volume terms in groups vs per request, max abs difference {err:.3e}; requests one per wave {st_g.gather_single} vs {st_q.gather_single}; "
+              f"device {st_g.kernel_ms:.2f} vs {st_q.kernel_ms:.2f} ms")
+        assert st_q.gather_single > 50000 and st_g.gather_single < st_q.gather_single // 4
+        assert err < 2e-6 * max(1.0, np.abs(single).max())
+    finally:
+        gpu_ctx.photons_upload(np.zeros((0, 9)), which=0)
         gpu_ctx.photons_upload(np.zeros((0, 9)), which=1)
 
 

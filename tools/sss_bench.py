@@ -15,7 +15,7 @@ n_emit = int(os.environ.get("SSS_EMIT", "200000"))
 (ns, nv), est = ctx.emit_photon_maps(n_emit, seed=12345)
 print(f"photons: {ns} surface, {nv} volume")
 cam = rt.look_at((2.8, 0, 0), (0, 0, 0))
-for k in (1000, 100):
+for k in [int(x) for x in os.environ.get("SSS_KS", "1000,100").split(",")]:
     p = rt.default_params(width=1920, height=1080, photon_num=n_emit, photon_use=k)
     best = None
     for _ in range(3):
