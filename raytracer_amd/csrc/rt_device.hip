@@ -1752,11 +1752,11 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
                     v[rtg::TP_C_GUESS] / nr, v[rtg::TP_C_WALK] / nr, v[rtg::TP_C_COUNT] / nr, v[rtg::TP_C_SORT] / nr, v[rtg::TP_C_PACK] / nr, v[rtg::TP_C_KTH] / nr,
                     v[rtg::TP_A_NOGUESS] / nr, v[rtg::TP_A_LISTS] / nr, v[rtg::TP_A_FEW] / nr, v[rtg::TP_A_MANY] / nr, v[rtg::TP_A_PACK] / nr);
         if (packed)
-            fprintf(stderr, "  windows by rounds taken (<= 1, 2, 3, 4 and more): %llu / %llu / %llu / %llu, mean cycles %.0f / %.0f / %.0f / %.0f, longest window %llu; kernel span first wave's start to last wave's end %llu cycles\n",
+            fprintf(stderr, "  windows by rounds taken (<= 1, 2, 3, 4 and more): %llu / %llu / %llu / %llu, mean cycles %.0f / %.0f / %.0f / %.0f, longest window %llu (%llu rounds, %llu attempts at a radius, %llu steps); kernel span first wave's start to last wave's end %llu cycles\n",
                     v[rtg::TP_W_ROUNDS1], v[rtg::TP_W_ROUNDS2], v[rtg::TP_W_ROUNDS3], v[rtg::TP_W_ROUNDS4],
                     v[rtg::TP_W_CYC1] / (double)std::max<unsigned long long>(1, v[rtg::TP_W_ROUNDS1]), v[rtg::TP_W_CYC2] / (double)std::max<unsigned long long>(1, v[rtg::TP_W_ROUNDS2]),
                     v[rtg::TP_W_CYC3] / (double)std::max<unsigned long long>(1, v[rtg::TP_W_ROUNDS3]), v[rtg::TP_W_CYC4] / (double)std::max<unsigned long long>(1, v[rtg::TP_W_ROUNDS4]),
-                    v[rtg::TP_W_MAX], v[rtg::TP_W_LAST_MAX] - v[rtg::TP_W_FIRST_MIN]);
+                    v[rtg::TP_W_MAX] >> 24, (v[rtg::TP_W_MAX] >> 16) & 255, (v[rtg::TP_W_MAX] >> 8) & 255, (v[rtg::TP_W_MAX] & 255) * 4, v[rtg::TP_W_LAST_MAX] - v[rtg::TP_W_FIRST_MIN]);
         fprintf(stderr, "group gather (k=%d): %llu windows, %llu rounds, %.1f requests and %.1f steps of 64 photons per round (hist %.1f, crit %.1f, sum %.1f steps); "
                         "cycles per round: kth %.0f, walk %.0f, hist %.0f, crit %.0f, rank %.0f, sum %.0f; requests handed on: %llu other materials, %llu in small rounds, "
                         "%llu box too large, %llu range too low, %llu range too high or crowded bin, %llu left after the last round, %llu ties to split; busy cycles per wave: mean %.0f, longest %llu\n",

@@ -38,7 +38,10 @@ constexpr int S_ATTEMPTS = 7;         // guesses at the centre's radius per roun
 constexpr int S_ATTEMPTS_VOLUME = 4;  // the same in a volume phase of a subsurface window (whose wave has three more phases to see to)
 constexpr int S_FLIGHT = 8;           // 64-photon steps of a streaming loop whose loads are in flight together
 constexpr int CONT_SHARDS = 8;        // lists of window parts handed from wave to wave (TileArgs::cont)
-constexpr int S_LEVEL = 320;          // subtrees of one tree level a group's box may touch
+constexpr int S_LEVEL = 384;          // subtrees of one tree level a group's box may touch
+constexpr int S_LEAVES = 448;         // leaves it may touch (what the per-lane tables of the passes leave room for: see StreamLds)
+constexpr int S_SSS_ATTEMPTS = 10;    // ... walks for a guessed radius, all its rounds together (one per round is the common case)
+constexpr int S_SSS_STEPS = 320;      // ... and steps of 64 photons its rounds may stream per pass, all together, before another round is begun
 constexpr int S_SSS_TRIES = 8;        // rounds a window with subsurface requests may take, its surface and volume phases together
 constexpr int S_CELL = 512;           // photons in the tree cell whose density gives the first guess
 
@@ -48,7 +51,7 @@ struct StreamLds {
     union {
         uint32_t table[(T_BINS / 2) * WAVE];      // histograms: [bin][32 words], two 16-bit counts each; critical bin: [T_CRIT][64]
         struct {
-            uint32_t leaf[T_LEAVES], piv[T_PIVOTS];           // as the walk lists them: by tree level, left to right
+            uint32_t leaf[S_LEAVES], piv[T_PIVOTS];           // as the walk lists them: by tree level, left to right
             int a_lo[S_LEVEL], a_hi[S_LEVEL];                 // the subtrees of the level being looked at
             int b_lo[S_LEVEL], b_hi[S_LEVEL];                 // those of the level below, in the making
         } w;
@@ -114,7 +117,7 @@ __device__ __attribute__((noinline)) int stream_walk(PhotonMapView pm, float glx
             }
             const unsigned long long m_leaf = __ballot(is_leaf), m_piv = __ballot(piv_in), m_l = __ballot(go_l), m_r = __ballot(go_r);
             const int c_leaf = __builtin_popcountll(m_leaf), c_piv = __builtin_popcountll(m_piv), c_l = __builtin_popcountll(m_l), c_r = __builtin_popcountll(m_r);
-            if (n_leaf + c_leaf > T_LEAVES || n_piv + c_piv > T_PIVOTS || n_next + c_l + c_r > S_LEVEL) return -1;
+            if (n_leaf + c_leaf > S_LEAVES || n_piv + c_piv > T_PIVOTS || n_next + c_l + c_r > S_LEVEL) return -1;
             if (is_leaf) S.w.leaf[n_leaf + (int)prefix_rank(m_leaf)] = ((uint32_t)rlo << 7) | (uint32_t)(rhi - rlo);
             if (piv_in) S.w.piv[n_piv + (int)prefix_rank(m_piv)] = (uint32_t)mid;
             const int at = n_next + (int)prefix_rank(m_l) + (int)prefix_rank(m_r);      // children of the lanes before this one
@@ -824,6 +827,8 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
         const bool volume_here = SSS && ta.sss_surface > 1;
         bool sss_wait = false;
         int tries = 0;      // rounds begun, all phases together
+        int work = 0;       // steps of 64 photons per pass, all rounds together
+        int w_attempts = 0; // guesses at a centre's radius, all rounds together
         float vol_r_here = -1.f, vol_cx = 0.f, vol_cy = 0.f, vol_cz = 0.f;      // the last volume round of this window: its centre and k-th distance
         double surf0 = 0, surf1 = 0, surf2 = 0, vol0 = 0, vol1 = 0, vol2 = 0;
         for (int phase = 0; phase < (SSS ? 4 : 1); phase++) {
@@ -873,8 +878,10 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
             }
             // A window of subsurface requests is one wave's from its first phase to its last, and the longest such window is the
             // least the kernel takes: past S_SSS_TRIES rounds (four phases of one round each is the common case, of two across a
-            // silhouette) what still waits goes to the per-request kernel.
-            if (keep_whole && ++tries > S_SSS_TRIES) {
+            // silhouette), or S_SSS_STEPS steps of 64 photons streamed by a pass (120 in the common case; several times that where
+            // the balls are wide -- the unlit side of an object, whose few photons lie far apart), what still waits goes to the
+            // per-request kernel, which spreads it over as many waves as there are requests.
+            if (keep_whole && (++tries > S_SSS_TRIES || work > S_SSS_STEPS)) {
                 TILE_COUNT(TP_R_LEFT, todo);
                 redo = redo || todo;
                 todo = false;
@@ -901,6 +908,9 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                 float too_small = 0.f, too_large = 3.0e38f;      // radii that held fewer than k photons / overflowed the lists
                 for (int attempt = 0; attempt < (volume ? S_ATTEMPTS_VOLUME : S_ATTEMPTS) && !found; attempt++) {
                     if (PROF) pr[TP_N_HIST]++;
+                    // (a subsurface window: no more than S_SSS_ATTEMPTS walks, all its rounds together -- where the balls are so wide
+                    // that the lists barely hold them every walk is a long one, and a failed round costs several)
+                    if (keep_whole && ++w_attempts > S_SSS_ATTEMPTS) break;
                     const float R = fminf(guess, r_max);
                     const bool whole = !(R < r_max);                            // the search radius itself: nothing larger to try
                     const bool cand = near && d_c <= R;                         // who can be in the round if r_c <= R
@@ -1033,6 +1043,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                 __builtin_amdgcn_wave_barrier();
             }
             const int n_steps = (n_pack + WAVE - 1) / WAVE;
+            work += n_steps;
             rounds_done++;
             if (PROF) pr[TP_ROUNDS]++; if (PROF) pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_steps; if (PROF) pr[TP_N_SUM] += n_pack;
 
@@ -1174,7 +1185,9 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
             else if (rounds_done == 2) { pr[TP_W_ROUNDS2]++; pr[TP_W_CYC2] += dt; }
             else if (rounds_done == 3) { pr[TP_W_ROUNDS3]++; pr[TP_W_CYC3] += dt; }
             else { pr[TP_W_ROUNDS4]++; pr[TP_W_CYC4] += dt; }
-            if (dt > pr[TP_W_MAX]) pr[TP_W_MAX] = dt;
+            // (the longest window with what it did, in one word that a maximum can be taken of: cycles, rounds completed, attempts at a radius, steps / 4)
+            const unsigned long long what = (dt << 24) | ((unsigned long long)(rounds_done & 255) << 16) | ((unsigned long long)(w_attempts & 255) << 8) | (unsigned long long)(work / 4 > 255 ? 255 : work / 4);
+            if (what > pr[TP_W_MAX]) pr[TP_W_MAX] = what;
         }
         // ---- requests left to the per-request kernel
         const unsigned long long m_redo = __ballot(redo);
