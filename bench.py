@@ -584,6 +584,26 @@ def other_configs(rt, ctx, torch, dev, prof_all, skip_c5=False):
     out["water_photon_map_1920x1080_k1000"]["roofline"]["frac_of_f32_rate"] = round(tf / VALU_PEAK_TFLOPS["f32"], 4)
     attach_profile(out["water_photon_map_1920x1080_k1000"]["roofline"], prof_all, "c4", ("gather_tile_kernel", "gather_stream_kernel", "gather_alongside_kernel", "gather_kernel"),
                    {"gather_tile_kernel": 1, "gather_stream_kernel": 1, "gather_alongside_kernel": 1, "gather_kernel": 1})
+    # the reference's default material (main.cpp:652, the class of BASELINE's first configuration) at the size of the
+    # others: every diffuse hit on the teapot asks four gathers -- one in the surface map, three in the volume map
+    s1 = rt.Scene()
+    s1.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.9, 0.7, 0.6, -1.0), 1.3, (0, -0.7, 0))
+    s1.add_cornell(); s1.build_bvh()
+    ctx.upload(s1)
+    n_emit = 200000
+    (ns, nv), est = ctx.emit_photon_maps(n_emit, seed=12345)
+    st = best(rt.default_params(width=w, height=h, photon_num=n_emit, photon_use=1000), w, h, reps=2)
+    os.environ["RT_SSS_VOLUME_PER_REQUEST"] = "1"      # (the library's comparison switch, read at every launch)
+    try:
+        st_pr = best(rt.default_params(width=w, height=h, photon_num=n_emit, photon_use=1000), w, h, reps=2)
+    finally:
+        del os.environ["RT_SSS_VOLUME_PER_REQUEST"]
+    out["subsurface_teapot_1920x1080_k1000"] = {
+        "photons_stored": {"surface": int(ns), "volume": int(nv)}, "gathers": int(st.gather_queries), "answered_one_per_wave": int(st.gather_single),
+        "device_ms": round(st.kernel_ms, 2), "trace_shade_ms": round(st.trace_kernel_ms, 2),
+        "device_ms_volume_terms_per_request": round(st_pr.kernel_ms, 2),
+        "note": "surface estimate and the three volume terms of a subsurface request answered by the group kernel"}
+    ctx.photons_upload(np.zeros((0, 9)), which=1)
     if not skip_c5:
         out["instanced_teapots_10M_triangles_7680x4320_16spp"] = config5(rt, ctx, torch, dev, prof_all)
     return out

@@ -1704,7 +1704,10 @@ int launch_gather(rt_context* ctx, const rtg::GatherRec* recs, const rtq::Counts
     // The per-request kernel alongside, on the second stream.  Its waves stay only once every wave of the group kernel
     // has begun, so they never hold a place the group kernel waits for; six blocks per CU leave room for one of the
     // group kernel's in any case.
-    const bool alongside = (!sss_scene || packed) && !getenv("RT_GATHER_NO_ALONGSIDE");      // (the switch: comparison runs; the earlier group form has no fence before its hand-overs)
+    // (the switch: comparison runs.  Not in subsurface scenes with the earlier group form, which has no fence before its hand-overs,
+    // nor with the volume terms left per request, the form that comparison is meant to show: every such request is then handed
+    // over, and 96 000 of them taken one at a time beside the group kernel took 13.9 ms where the launch after it takes 11.5)
+    const bool alongside = (!sss_scene || (packed && sss_mode == 2)) && !getenv("RT_GATHER_NO_ALONGSIDE");
     if (alongside) {
         HIP_TRY(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
         hipLaunchKernelGGL(rtg::gather_alongside_kernel, dim3(ctx->num_cus * 6), dim3(rtg::WAVE), 0, ctx->side, ctx->pm[0], ctx->pm[1], recs, d_redo,
