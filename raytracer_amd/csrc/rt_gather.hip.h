@@ -604,6 +604,75 @@ __device__ __forceinline__ Cand knn_collect_from(const PhotonMapView& pm, float 
     return c;
 }
 
+constexpr int S_FLIGHT = 8;           // 64-photon steps of a streaming loop whose loads are in flight together
+constexpr int S_CELL = 512;           // photons in the tree cell whose density gives a first guess at a k-th distance
+
+__device__ __forceinline__ float wave_min_f(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v)
+{
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// 16 bytes read as GLOBAL memory (a pointer of unknown address space makes it a flat load, which every wait for an LDS
+// read in the loops would wait for, too)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load_global4(const float4* p)
+{
+    const v4f v = *(const v4f __attribute__((address_space(1)))*)p;
+    return float4{v.x, v.y, v.z, v.w};
+}
+
+// ---- a first guess at a point's k-th nearest distance from the photon density around it: the cell (subtree) of at most
+// S_CELL photons that holds the centre is a box whose photons -- points on a surface -- fill its bounding box, so their
+// number over the box's face area (its two largest extents) is the density there, and r_k ~ sqrt(k / (pi density)).
+// The guess only has to be close: what the walk then lists is counted, and a second walk corrects a bad one.
+// (`volume`: the map of photons scattered inside a subsurface material.  Where they fill the cell's box the density is
+// their number over its volume and r_k ~ cbrt(3 k / (4 pi density)); where they lie in a thin layer under the lit surface,
+// as they do when the free path is short, the surface form holds.  The larger of the two: a guess too small costs a
+// second walk, one too large only a longer list for the filter to cut down.)
+__device__ __attribute__((noinline)) float radius_guess(PhotonMapView pm, float cx, float cy, float cz, int k, bool volume)
+{
+    const int lane = lane_id();
+    int lo = 0, hi = (int)pm.n;
+    while (hi - lo > S_CELL) {
+        const int mid = lo + (hi - lo) / 2;
+        const float4 pv = pm.pos[mid];
+        const int ax = (int)pv.w;
+        const float split = ax == 0 ? pv.x : (ax == 1 ? pv.y : pv.z);
+        const float delta = (ax == 0 ? cx : (ax == 1 ? cy : cz)) - split;
+        if (delta < 0.f) hi = mid; else lo = mid + 1;
+    }
+    if (hi - lo < 16) return 0.f;
+    static_assert(S_CELL <= S_FLIGHT * WAVE, "one batch of loads covers the cell");
+    float4 p[S_FLIGHT];
+#pragma unroll
+    for (int u = 0; u < S_FLIGHT; u++) {
+        const int i = lo + u * WAVE + lane;
+        p[u] = load_global4(pm.pos + (i < hi ? i : hi - 1));      // (a repeated photon changes no bound)
+    }
+    float nx = p[0].x, ny = p[0].y, nz = p[0].z, xx = nx, xy = ny, xz = nz;
+#pragma unroll
+    for (int u = 1; u < S_FLIGHT; u++) {
+        nx = fminf(nx, p[u].x); ny = fminf(ny, p[u].y); nz = fminf(nz, p[u].z);
+        xx = fmaxf(xx, p[u].x); xy = fmaxf(xy, p[u].y); xz = fmaxf(xz, p[u].z);
+    }
+    const float ex = wave_max_f(xx) - wave_min_f(nx), ey = wave_max_f(xy) - wave_min_f(ny), ez = wave_max_f(xz) - wave_min_f(nz);
+    const float e_max = fmaxf(ex, fmaxf(ey, ez)), e_min = fminf(ex, fminf(ey, ez)), e_mid = ex + ey + ez - e_max - e_min;
+    const float area = e_max * e_mid;
+    if (volume) {
+        if (!(area > 0.f)) return 0.f;
+        const float vol = area * e_min;
+        return fmaxf(cbrtf(3.f * (float)k * vol / (4.f * 3.14159265f * (float)(hi - lo))), sqrtf((float)k * area / (3.14159265f * (float)(hi - lo))));
+    }
+    if (!(area > 0.f)) return 0.f;
+    return sqrtf((float)k * area / (3.14159265f * (float)(hi - lo)));
+}
+
 // State a wave carries from one query to the next.  Queries arrive in runs of neighbouring hit
 // points (one 8x8 pixel tile appends its requests together), and the k-th nearest distance obeys
 // the triangle inequality: r_k(q') <= r_k(q) + |q' - q|.  So a query that found its k photons hands
@@ -614,9 +683,14 @@ struct Neighbour {
     float radius;     // k-th nearest distance of the previous query; < 0: none
 };
 
+// A query with no neighbour to go by -- an isolated hit point, or the first of a run -- starts from a GUESSED bound instead:
+// the radius the photon density around it suggests (radius_guess) and a margin.  A guess that holds k photons saves the
+// first scan and the selects that shrink an unknown bound step by step (216 k -> about half the cycles per isolated
+// query at k = 1000); one that holds fewer is widened by the count just taken, and the search radius itself is the last
+// resort, so the set returned is the exact one in every case.
 template <bool IDS = true>
 __device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, float qy, float qz, int k, float r2, int front_cap, Prof pf,
-                                           Neighbour* nb = nullptr)
+                                           Neighbour* nb = nullptr, bool volume_map = false)
 {
     float hint = 0.f;
     if (nb && nb->radius >= 0.f) {
@@ -624,11 +698,25 @@ __device__ __forceinline__ int knn_collect(const PhotonMapView& pm, float qx, fl
         float reach = nb->radius + sqrtf(dx * dx + dy * dy + dz * dz);
         hint = reach * reach * 1.001f + 1e-12f;       // slack for the rounding of the distances
     }
-    Cand c = knn_collect_from<IDS>(pm, qx, qy, qz, k, r2, hint, front_cap, pf);
-    if (hint > 0.f && hint < r2 && c.count < k) {
-        // cannot happen in exact arithmetic; never return a short set because of a hint
+    bool guessed = false;
+    if (!(hint > 0.f && hint < r2)) {
+        const float g = radius_guess(pm, qx, qy, qz, k, volume_map) * 1.15f;
+        if (g > 0.f && g * g < r2) { hint = g * g; guessed = true; }
+    }
+    Cand c{0, r2, 0};
+    for (int attempt = 0;; attempt++) {      // (one call site: the search is inlined)
+        c = knn_collect_from<IDS>(pm, qx, qy, qz, k, r2, hint, front_cap, pf);
+        if (c.count >= k || !(hint > 0.f && hint < r2)) break;      // (a search bounded by the search radius alone is final)
+        if (guessed && attempt < 2) {
+            // a guess that holds too few: widened by the count just taken (the photons in reach go with the radius squared
+            // on a surface -- with `hint`, that is; a volume's go faster)
+            const float ratio = (float)k / (float)(c.count > 0 ? c.count : 1);
+            hint *= fminf(ratio * 1.3f, 9.f);
+        } else {
+            // the last resort; for a neighbour's bound this cannot happen in exact arithmetic -- never a short set because of a hint
+            hint = 0.f;
+        }
         __builtin_amdgcn_wave_barrier();
-        c = knn_collect_from<IDS>(pm, qx, qy, qz, k, r2, 0.f, front_cap, pf);
     }
     if (nb) {
         nb->x = qx; nb->y = qy; nb->z = qz;
@@ -815,7 +903,7 @@ __device__ __forceinline__ void answer_request(const PhotonMapView& pm, const Ph
         const float hp[3] = {(float)r.pos[0], (float)r.pos[1], (float)r.pos[2]};
         double sss[3] = {0, 0, 0};
         __builtin_amdgcn_wave_barrier();
-        int vc = knn_collect(vm, hp[0], hp[1], hp[2], gp.k, gp.r2, gp.front_cap, pf, &nbv);
+        int vc = knn_collect(vm, hp[0], hp[1], hp[2], gp.k, gp.r2, gp.front_cap, pf, &nbv, true);
         __builtin_amdgcn_wave_barrier();
         volume_step(vm, vc, hp, r.color, 1.0, gp.photon_num, sss);
         if (r.flags & GATHER_MARCH) {
@@ -823,7 +911,7 @@ __device__ __forceinline__ void answer_request(const PhotonMapView& pm, const Ph
             double e_pass = 2.71828;
             for (int pass = 1; pass < 3; pass++) {
                 __builtin_amdgcn_wave_barrier();
-                vc = knn_collect(vm, (float)px, (float)py, (float)pz, gp.k, gp.r2, gp.front_cap, pf, &nbv);
+                vc = knn_collect(vm, (float)px, (float)py, (float)pz, gp.k, gp.r2, gp.front_cap, pf, &nbv, true);
                 __builtin_amdgcn_wave_barrier();
                 volume_step(vm, vc, hp, r.color, e_pass, gp.photon_num, sss);
                 // the stream is keyed by what identifies the request whatever the launch: pixel, hit point, pass

@@ -36,14 +36,12 @@ namespace rtg {
 constexpr int S_PACK_CAP = 8192;      // photons the packed list of a wave holds at most (16 bytes each); TileArgs::pack_cap is the size in use
 constexpr int S_ATTEMPTS = 7;         // guesses at the centre's radius per round before the round is handed on
 constexpr int S_ATTEMPTS_VOLUME = 4;  // the same in a volume phase of a subsurface window (whose wave has three more phases to see to)
-constexpr int S_FLIGHT = 8;           // 64-photon steps of a streaming loop whose loads are in flight together
 constexpr int CONT_SHARDS = 8;        // lists of window parts handed from wave to wave (TileArgs::cont)
 constexpr int S_LEVEL = 384;          // subtrees of one tree level a group's box may touch
 constexpr int S_LEAVES = 448;         // leaves it may touch (what the per-lane tables of the passes leave room for: see StreamLds)
 constexpr int S_SSS_ATTEMPTS = 10;    // ... walks for a guessed radius, all its rounds together (one per round is the common case)
 constexpr int S_SSS_STEPS = 320;      // ... and steps of 64 photons its rounds may stream per pass, all together, before another round is begun
 constexpr int S_SSS_TRIES = 8;        // rounds a window with subsurface requests may take, its surface and volume phases together
-constexpr int S_CELL = 512;           // photons in the tree cell whose density gives the first guess
 
 // Per-wave LDS of the kernel: 12.5 KB, so that twelve waves share a CU.  The per-lane tables of the passes lie over
 // what the walk and the sort of its lists need, which is dead once the packed list exists.
@@ -60,15 +58,6 @@ struct StreamLds {
 };
 static_assert(T_CRIT * WAVE <= (T_BINS / 2) * WAVE && sizeof(StreamLds) <= 13 * 1024, "twelve waves per CU");
 __shared__ StreamLds g_S;
-
-// 16 bytes read as GLOBAL memory (a pointer of unknown address space makes it a flat load, which every wait for an LDS
-// read in the loops would wait for, too)
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 load_global4(const float4* p)
-{
-    const v4f v = *(const v4f __attribute__((address_space(1)))*)p;
-    return float4{v.x, v.y, v.z, v.w};
-}
 
 __device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int src)
 {
@@ -305,52 +294,6 @@ __device__ __attribute__((noinline)) int pack_refilter(float4* pack, int n_pack,
         __builtin_amdgcn_wave_barrier();
     }
     return out;
-}
-
-// ---- a first guess at the centre's k-th distance from the photon density around it: the cell (subtree) of at most
-// S_CELL photons that holds the centre is a box whose photons -- points on a surface -- fill its bounding box, so their
-// number over the box's face area (its two largest extents) is the density there, and r_k ~ sqrt(k / (pi density)).
-// The guess only has to be close: what the walk then lists is counted, and a second walk corrects a bad one.
-// (`volume`: the map of photons scattered inside a subsurface material.  Where they fill the cell's box the density is
-// their number over its volume and r_k ~ cbrt(3 k / (4 pi density)); where they lie in a thin layer under the lit surface,
-// as they do when the free path is short, the surface form holds.  The larger of the two: a guess too small costs a
-// second walk, one too large only a longer list for the filter to cut down.)
-__device__ __attribute__((noinline)) float centre_guess(PhotonMapView pm, float cx, float cy, float cz, int k, bool volume)
-{
-    const int lane = lane_id();
-    int lo = 0, hi = (int)pm.n;
-    while (hi - lo > S_CELL) {
-        const int mid = lo + (hi - lo) / 2;
-        const float4 pv = pm.pos[mid];
-        const int ax = (int)pv.w;
-        const float split = ax == 0 ? pv.x : (ax == 1 ? pv.y : pv.z);
-        const float delta = (ax == 0 ? cx : (ax == 1 ? cy : cz)) - split;
-        if (delta < 0.f) hi = mid; else lo = mid + 1;
-    }
-    if (hi - lo < 16) return 0.f;
-    static_assert(S_CELL <= S_FLIGHT * WAVE, "one batch of loads covers the cell");
-    float4 p[S_FLIGHT];
-#pragma unroll
-    for (int u = 0; u < S_FLIGHT; u++) {
-        const int i = lo + u * WAVE + lane;
-        p[u] = load_global4(pm.pos + (i < hi ? i : hi - 1));      // (a repeated photon changes no bound)
-    }
-    float nx = p[0].x, ny = p[0].y, nz = p[0].z, xx = nx, xy = ny, xz = nz;
-#pragma unroll
-    for (int u = 1; u < S_FLIGHT; u++) {
-        nx = fminf(nx, p[u].x); ny = fminf(ny, p[u].y); nz = fminf(nz, p[u].z);
-        xx = fmaxf(xx, p[u].x); xy = fmaxf(xy, p[u].y); xz = fmaxf(xz, p[u].z);
-    }
-    const float ex = wave_max_f(xx) - wave_min_f(nx), ey = wave_max_f(xy) - wave_min_f(ny), ez = wave_max_f(xz) - wave_min_f(nz);
-    const float e_max = fmaxf(ex, fmaxf(ey, ez)), e_min = fminf(ex, fminf(ey, ez)), e_mid = ex + ey + ez - e_max - e_min;
-    const float area = e_max * e_mid;
-    if (volume) {
-        if (!(area > 0.f)) return 0.f;
-        const float vol = area * e_min;
-        return fmaxf(cbrtf(3.f * (float)k * vol / (4.f * 3.14159265f * (float)(hi - lo))), sqrtf((float)k * area / (3.14159265f * (float)(hi - lo))));
-    }
-    if (!(area > 0.f)) return 0.f;
-    return sqrtf((float)k * area / (3.14159265f * (float)(hi - lo)));
 }
 
 // ---- the centre's k-th smallest squared distance among the packed photons with d2 < lim, by all lanes together:
@@ -901,7 +844,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                     const float mx = cx - vol_cx, my = cy - vol_cy, mz = cz - vol_cz;
                     guess = (vol_r_here + sqrtf(mx * mx + my * my + mz * mz)) * 1.02f;
                 } else {
-                    TILE_PROF(TP_C_GUESS, guess = centre_guess(map, cx, cy, cz, gp.k, volume) * 1.15f);
+                    TILE_PROF(TP_C_GUESS, guess = radius_guess(map, cx, cy, cz, gp.k, volume) * 1.15f);
                 }
                 const float prev = volume ? prev_r_vol : prev_r;
                 if (!(guess > 0.f)) { guess = prev > 0.f ? prev * 1.2f : r_max * 0.3f; if (PROF) pr[TP_A_NOGUESS]++; }

@@ -103,17 +103,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));   // two photons per packe
 
 __device__ __forceinline__ float bcast(float v, int src) { return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), src)); }
 
-__device__ __forceinline__ float wave_min_f(float v)
-{
-    for (int off = 32; off > 0; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ float wave_max_f(float v)
-{
-    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
-    return v;
-}
-
 // a pointer of unknown address space as one into global memory
 __device__ __forceinline__ const float __attribute__((address_space(1)))* as_global(const float* p)
 {
