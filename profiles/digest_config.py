@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DST = os.path.join(ROOT, "profiles")
 FAMILIES = ("trace_primary_kernel<double, false", "trace_primary_kernel<float, false", "render_primary_kernel", "trace_queue_kernel", "shade_kernel",
-            "gather_tile_kernel", "gather_alongside_kernel", "gather_kernel", "gather_stream_kernel", "emit_kernel", "resolve_kernel")
+            "gather_tile_kernel", "gather_alongside_kernel", "gather_kernel", "gather_stream_kernel", "gather_stream_sss_kernel", "emit_kernel", "resolve_kernel")
 
 
 def family(kernel):

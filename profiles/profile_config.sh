@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel times and hardware counters of one bench configuration, on the GPU box (through gpurun, from the repo root):
-#   bash profiles/profile_config.sh <tag> <c2|c3|c4|c5>
+#   bash profiles/profile_config.sh <tag> <c2|c3|c4|c5|sss>
 # 1. rocprofv3 --kernel-trace --stats over tools/pmc_run.py <cfg>; 2. one rocprofv3 --pmc run per counter group (never
 # combined with tracing), the program directly after `--`.  Results under gpurun_out/prof_<tag>_<cfg>/; condense them
 # into profiles/ with `python3 profiles/digest_config.py <tag> <cfg>` afterwards.

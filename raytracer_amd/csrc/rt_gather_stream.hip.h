@@ -70,7 +70,10 @@ __device__ __forceinline__ unsigned long long bcast64(unsigned long long v, int 
 // (a lane's children go to the next level's list side by side, in the lanes' order), so the lists come out ordered by
 // (level, tree position): two walks for different boxes list what they have in common in the same order, which is
 // what makes the packed list -- and the order of the sums over it -- a function of the final box alone.
-__device__ __attribute__((noinline)) int stream_walk(PhotonMapView pm, float glx, float gly, float glz, float ghx, float ghy, float ghz)
+// Of the leaves inside the box only those within sqrt(reach2) of the centre c are listed (by their bounding boxes: the distance
+// formed like a photon's from offsets no larger in magnitude, so it never exceeds that of a photon inside): the packing
+// keeps nothing beyond that reach, and the corners of the box hold a fifth of its leaves.
+__device__ __attribute__((noinline)) int stream_walk(PhotonMapView pm, float glx, float gly, float glz, float ghx, float ghy, float ghz, float cx, float cy, float cz, float reach2)
 {
     StreamLds& S = g_S;
     const int lane = lane_id();
@@ -90,6 +93,8 @@ __device__ __attribute__((noinline)) int stream_walk(PhotonMapView pm, float glx
             if (is_leaf) {
                 const float* b = pm.leaf_box + 6 * (size_t)(rlo >> 5);
                 is_leaf = !(b[0] > ghx || b[3] < glx || b[1] > ghy || b[4] < gly || b[2] > ghz || b[5] < glz);
+                const float ex = fmaxf(fmaxf(b[0] - cx, cx - b[3]), 0.f), ey = fmaxf(fmaxf(b[1] - cy, cy - b[4]), 0.f), ez = fmaxf(fmaxf(b[2] - cz, cz - b[5]), 0.f);
+                is_leaf = is_leaf && ex * ex + ey * ey + ez * ez <= reach2;
             }
             const bool is_inner = live && !small;
             int mid = 0;
@@ -865,7 +870,7 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
                     const float reach = wave_max_f(cand ? d_c : 0.f) + rad;
                     __builtin_amdgcn_wave_barrier();
                     int lists;
-                    TILE_PROF(TP_C_WALK, lists = stream_walk(map, glx, gly, glz, ghx, ghy, ghz));
+                    TILE_PROF(TP_C_WALK, lists = stream_walk(map, glx, gly, glz, ghx, ghy, ghz, cx, cy, cz, reach * reach * 1.0001f));
                     if (lists < 0) {
                         if (PROF) pr[TP_A_LISTS]++;
                         // too much of the tree: a smaller radius, unless that is known to hold fewer than k photons

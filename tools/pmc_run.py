@@ -4,6 +4,8 @@ counters per run) to time and count what the kernels of that configuration do (p
       precision, double then float), exactly the launches bench.py times
   c3  glass teapot 3840x2160, depth 4, no photon map        (render_primary / shade / trace_queue kernels)
   c4  water + Cornell box, 1 M photons emitted on the device, k = 1000, 1920x1080   (gather kernels)
+  sss the subsurface teapot (the reference's default material) + Cornell box, 200 000 photons emitted on the device (surface
+      and volume maps), k = 1000, 1920x1080   (gather kernels, subsurface instantiation)
   c5  the 10 M-triangle frame of bench.py: C5_INST teapots on a grid (default 10 000), the reference's tree built on the
       host (C5_TREE=lbvh: the device-built tree), 7680x4320, 16 samples per pixel, double precision (C5_PREC=f32: float).
       The host build takes 16 s, so the first run leaves the flat image of the scene in C5_IMAGE (default
@@ -52,6 +54,13 @@ def main():
         ctx.emit_photon_maps(1000000, seed=12345)
         w, h = 1920, 1080
         p = rt.default_params(width=w, height=h, photon_num=1000000, photon_use=int(os.environ.get("C4_K", "1000")))
+        cam = CAM
+    elif which == "sss":
+        s.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.9, 0.7, 0.6, -1.0), 1.3, (0, -0.7, 0))
+        s.add_cornell(); s.build_bvh(); ctx.upload(s)
+        ctx.emit_photon_maps(200000, seed=12345)
+        w, h = 1920, 1080
+        p = rt.default_params(width=w, height=h, photon_num=200000, photon_use=int(os.environ.get("C4_K", "1000")))
         cam = CAM
     else:
         n_inst = int(os.environ.get("C5_INST", "10000"))
