@@ -680,6 +680,8 @@ __global__ __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(2, 2))) vo
                     clip3(rgb);                                    // main.cpp:391
                     for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
                 }
+            } else if (sss && act && !split_tie) {
+                redo = true;      // (no surface photon in reach: nothing to note, but the volume terms are still to come)
             }
             __builtin_amdgcn_wave_barrier();
         }

@@ -364,6 +364,37 @@ def test_subsurface_full_frame_volume_terms_in_groups(gpu_ctx, monkeypatch):
         gpu_ctx.photons_upload(np.zeros((0, 9)), which=1)
 
 
+def test_subsurface_without_surface_photons_in_reach(gpu_ctx, monkeypatch):
+    """Subsurface hit points with no photon of the surface map within the search radius (the map holds the photons of one
+    wall only): their surface estimate is zero, and their volume terms are still owed -- in both group forms as per request."""
+    g = golden("render_sss_64.npz")
+    s = build_scene(rt.Scene(), "teapot_normal.obj", tuple(g["rgbs"]), float(g["ior"]), (0, -0.7, 0))
+    s.emit_photons(20000, seed=12345)
+    gpu_ctx.upload(s)
+    surface = s.photons_get(0)
+    far = surface[surface[:, 0] < -0.95]
+    assert 200 < len(far) < len(surface)
+    gpu_ctx.photons_upload(far)
+    gpu_ctx.photons_upload(s.photons_get(1), which=1)
+    try:
+        cam = rt.look_at(CAM[:3], CAM[3:])
+        p = rt.default_params(width=160, height=120, photon_use=200)
+        monkeypatch.setenv("RT_GATHER_MODE", "query")
+        single, _, st_q = gpu_ctx.render(cam, p)
+        monkeypatch.delenv("RT_GATHER_MODE")
+        teapot = single[40:80, 60:100]
+        assert teapot.max() > 0.01                 # (volume terms alone light the teapot)
+        for form in ("stream", "tile"):
+            monkeypatch.setenv("RT_GATHER_FORM", form)
+            grouped, _, st_g = gpu_ctx.render(cam, p)
+            monkeypatch.delenv("RT_GATHER_FORM")
+            err = np.abs(grouped - single).max()
+            print(f"subsurface without surface photons in reach, form {form}: max abs difference {err:.3e}, {st_g.gather_single} of {st_g.gather_queries} one per wave")
+            assert err < 2e-6 * max(1.0, np.abs(single).max())
+    finally:
+        gpu_ctx.photons_upload(np.zeros((0, 9)), which=1)
+
+
 def _glossy_scene(api):
     api.load_obj(os.path.join(DATA, "teapot_normal.obj"), (0.5, 0.5, 0.5, 0.0), 1.0, (0, -0.7, 0))
     api.add_sphere((0.0, 0.35, 0.55), 0.3, (1.0, 1.0, 1.0, 0.987654), 1.0)      # glossy mirror (main.cpp:640)
