@@ -317,7 +317,7 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
     // the per-call counters are cleared only for a caller that reads them (an overflow is latched on the device either way)
     if (want_counts) HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
     int wpb = g.threads / 64;
-    int blocks = (int)rtk::tile_grid_blocks((a.width + 7) / 8, (a.row_end - a.row_begin + 7) / 8, wpb, g.mode == rtk::TRAV_NODES);
+    int blocks = (int)rtk::tile_grid_blocks((a.width + 7) / 8, (a.row_end - a.row_begin + 7) / 8, wpb, g.mode == rtk::TRAV_NODES, 1, rtk::tile_strata<R>());
 #define RT_LAUNCH_PRIMARY(MODE)                                                                                                              \
     if ((rc = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), g.lds))) return rc;     \
     hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, \
@@ -1793,7 +1793,7 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     const int cap = stack_cap(ctx);
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int wpb = g.threads / 64;
-    const dim3 grid((unsigned)rtk::tile_grid_blocks((a.col_end - a.col_begin + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth));
+    const dim3 grid((unsigned)rtk::tile_grid_blocks((a.col_end - a.col_begin + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth, rtk::tile_strata<R>()));
     int rc_lds;
     if (COUNT) {
         if ((rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::render_primary_kernel<R, TRI_ONLY, MODE, false, COUNT>), g.lds))) return rc_lds;

@@ -393,21 +393,27 @@ struct PrimaryArgs {
 //    (128 x 64 pixels) walked in Morton order, so the waves of a block look at neighbouring pixels and share
 //    triangle records in L1.  Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8, each
 //    with its own L2): XCD x takes super-blocks x, x + 8, ... and finishes each before the next.  3-5 % faster
-//    than rows of tiles on the teapot frames.
+//    than rows of tiles on the teapot frames.  An XCD's sequence of super-blocks runs down the frame, and a frame's
+//    upper and lower part are seldom alike (ceiling and far wall above, the objects and the floor below): with `strata`
+//    = 2 the sequence is taken from its first and its second half in turn, so that what is resident at any time is a
+//    mix of both.  The headline frame in double: 0.301 -> 0.283 ms; in float 2 % slower, as are 4, 8 and 16 strata in
+//    either precision (tile_strata).
 //  * rows of tiles (large scenes): consecutive waves take consecutive tiles of a row.  On the 10 M-triangle grid
 //    the compact order lowers L1/L2 misses but leaves fewer waves resident on average (3.0 instead of 3.6 per
 //    SIMD) and the frame takes 9 % longer, so such scenes keep this order.
 constexpr int SB_TX = 16, SB_TY = 8, SB_TILES = SB_TX * SB_TY, N_XCD = 8;
+template <class R> constexpr int tile_strata() { return sizeof(R) == 8 ? 2 : 1; }
 // (`split` consecutive waves share a tile: wave `*part` of them takes that share of the tile's samples)
-__host__ __device__ inline long long tile_grid_blocks(int tiles_x, int tiles_y, int waves_per_block, bool compact, int split = 1)
+__host__ __device__ inline long long tile_grid_blocks(int tiles_x, int tiles_y, int waves_per_block, bool compact, int split = 1, int strata = 1)
 {
     if (!compact) return ((long long)tiles_x * tiles_y * split + waves_per_block - 1) / waves_per_block;
     const long long n_sb = (long long)((tiles_x + SB_TX - 1) / SB_TX) * ((tiles_y + SB_TY - 1) / SB_TY);
-    const long long per_xcd = (n_sb + N_XCD - 1) / N_XCD * SB_TILES * split;         // waves (with padding) one XCD runs
+    const long long n_seq = ((n_sb + N_XCD - 1) / N_XCD + strata - 1) / strata * strata;      // super-blocks (with padding) in one XCD's sequence
+    const long long per_xcd = n_seq * SB_TILES * split;                                        // waves one XCD runs
     return (per_xcd + waves_per_block - 1) / waves_per_block * N_XCD;
 }
 template <bool COMPACT>
-__device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, int* ty, unsigned split = 1, int* part = nullptr)
+__device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, int* ty, unsigned split = 1, int* part = nullptr, unsigned strata = 1)
 {
     const unsigned wpb = blockDim.x >> 6;
     if (!COMPACT) {
@@ -423,9 +429,15 @@ __device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, 
     const unsigned long long w = (unsigned long long)slot * wpb + (threadIdx.x >> 6);
     const unsigned long long q = w / split;
     if (part) *part = (int)(w % split);
-    const unsigned long long sb = q / SB_TILES * N_XCD + xcd;
-    const unsigned m = (unsigned)(q % SB_TILES);
     const unsigned sbx = (unsigned)(tiles_x + SB_TX - 1) / SB_TX, sby = (unsigned)(tiles_y + SB_TY - 1) / SB_TY;
+    unsigned long long seq = q / SB_TILES;
+    if (strata > 1) {
+        const unsigned long long per = (((unsigned long long)sbx * sby + N_XCD - 1) / N_XCD + strata - 1) / strata;      // places in a stratum
+        if (seq >= per * strata) return false;
+        seq = (seq % strata) * per + seq / strata;
+    }
+    const unsigned long long sb = seq * N_XCD + xcd;
+    const unsigned m = (unsigned)(q % SB_TILES);
     if (sb >= (unsigned long long)sbx * sby) return false;
     // m = x3 y2 x2 y1 x1 y0 x0
     const unsigned mx = (m & 1) | ((m >> 1) & 2) | ((m >> 2) & 4) | ((m >> 3) & 8);
@@ -456,7 +468,7 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
     // blocks as earlier ones retire (a shared counter serves only ~90 requests per microsecond
     // chip-wide, which is fewer than the tiles this kernel retires)
     int tx, ty;
-    if (tile_of_wave<MODE == TRAV_NODES>(tiles_x, tiles_y, &tx, &ty)) {
+    if (tile_of_wave<MODE == TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, 1, nullptr, tile_strata<R>())) {
         int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
         if (x < a.width && yl < rows) {
             int yc = a.row_begin + yl;   // row in this call's (compact) row space
