@@ -176,6 +176,8 @@ def main():
     rays_per_step, elapsed, head_dev_ms = timed(params, args.steps, args.warmup)
     ms_per_step = elapsed / args.steps * 1e3
     value = rays_per_step / (ms_per_step * 1e-3) / 1e6
+    # the order the library settled on for this view's tiles (it times both on the first launches of a view and keeps the faster)
+    tile_strata = int(ctx.trace_primary_dev(cam, params, (0, part_rows), buf.data_ptr(), None, None, stats=True).tile_strata)
     node_b, prim_b = (128, 80) if prec == rt.RT_F64 else (64, 48)
     alg_bytes = st_work.inner_visits * node_b + st_work.prim_tests * prim_b
     rank_rays = st_work.primary_rays + st_work.shadow_rays
@@ -376,6 +378,8 @@ def main():
         "two_contexts_alternating": two_ctx,
         "cpu_baseline": cpu,
         "parity": parity,
+        "tile_order": {"strata": tile_strata, "note": "1: an XCD takes its super-blocks of tiles down the frame; 2: from the frame's two halves in turn.  Chosen per view by the library from "
+                       "timed launches of both orders among the first eight of the view (the warm-up here); same work and same frames either way"},
         "other_configs": extras,
         "strong_scaling": strong,
     }

@@ -136,6 +136,17 @@ struct rt_scene {
     std::vector<rth::PhotonRec> photons[2];   // 0 surface, 1 volume
 };
 
+// The order in which the camera-ray kernel takes a frame's tiles, chosen by measurement per view (see tile_order_of): which
+// of the two orders a launch of this frame used when it was timed, how long it took, and which one has won.
+constexpr int TILE_TUNE_ENTRIES = 8, TILE_TUNE_TRIALS = 4;
+struct TileTune {
+    uint64_t key = 0;                    // of scene, camera, frame and query
+    int decided = 0;                     // 0: still measuring; else the number of strata (1 or 2)
+    int started = 0;                     // timed launches begun: launch i runs between ev[2 i] and ev[2 i + 1] with 1 + i % 2 strata
+    hipEvent_t ev[4 * TILE_TUNE_TRIALS] = {};
+    uint64_t used = 0;                   // for replacement: the least recently used entry goes
+};
+
 struct rt_context {
     int device = 0;
     int num_cus = 0;
@@ -171,6 +182,9 @@ struct rt_context {
     DevBuf cont;              // window parts the group gather's waves hand to each other (rtg::TileArgs::cont)
     // staging for the host-buffer convenience entry points
     DevBuf st_org, st_dir, st_dist, st_ids, st_aux;
+    TileTune tile_tune[TILE_TUNE_ENTRIES];
+    uint64_t tile_tune_clock = 0;
+    uint64_t scene_generation = 0;       // counts the uploads: a new scene is a new view for tile_tune
 };
 
 namespace {
@@ -307,6 +321,60 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
     return view<R>(ctx).tri_only ? launch_batch_t<R, true>(ctx, n, d_org, d_dir, d_dist, d_ids) : launch_batch_t<R, false>(ctx, n, d_org, d_dir, d_dist, d_ids);
 }
 
+// How long the camera-ray kernel takes depends on which tiles are under way together (rtk::tile_of_wave), by 5-25 % between
+// the plain sequence and the one taken from the frame's two halves in turn, and which of the two is the faster depends on
+// the view.  So it is measured: the first 2 x TILE_TUNE_TRIALS launches of a view -- same scene, camera, frame and query --
+// alternate between the two orders, each inside its own pair of events; the launches after them take the plain order until
+// the last of those has finished (nobody waits: a caller that enqueues ahead of the device just stays with the plain order
+// a little longer), and from then on the order with the shortest launch is the view's.  RT_TILE_STRATA=<n> fixes the order
+// instead.  The frames are the same either way.
+uint64_t tile_view_key(const rt_context* ctx, const rtk::PrimaryArgs& a, int precision)
+{
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&h](const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; } };
+    mix(&ctx->scene_generation, sizeof ctx->scene_generation);
+    mix(a.cam_pos, sizeof a.cam_pos); mix(a.cam_dir, sizeof a.cam_dir); mix(a.cam_right, sizeof a.cam_right); mix(a.cam_down, sizeof a.cam_down);
+    mix(a.light, sizeof a.light);
+    const int v[] = {a.width, a.height, a.row_begin, a.row_end, a.shadow, a.band_rows, a.n_parts, a.part, precision};
+    mix(v, sizeof v);
+    return h ? h : 1;
+}
+
+// -> the strata this launch is to use; *ev0 / *ev1: the events it is to run between (null: untimed)
+int tile_order_of(rt_context* ctx, uint64_t key, hipEvent_t* ev0, hipEvent_t* ev1)
+{
+    *ev0 = *ev1 = nullptr;
+    TileTune* t = nullptr;
+    TileTune* oldest = &ctx->tile_tune[0];
+    for (auto& e : ctx->tile_tune) {
+        if (e.key == key) { t = &e; break; }
+        if (e.used < oldest->used) oldest = &e;
+    }
+    if (!t) {
+        t = oldest;
+        // (its events are about to be recorded anew: the launches they belong to have to be past them)
+        if (!t->decided && t->started > 0 && hipEventSynchronize(t->ev[2 * t->started - 1]) != hipSuccess) return 1;
+        t->key = key; t->decided = 0; t->started = 0;
+    }
+    t->used = ++ctx->tile_tune_clock;
+    if (t->decided) return t->decided;
+    if (t->started < 2 * TILE_TUNE_TRIALS) {
+        hipEvent_t& a = t->ev[2 * t->started];
+        hipEvent_t& b = t->ev[2 * t->started + 1];
+        if ((!a && hipEventCreate(&a) != hipSuccess) || (!b && hipEventCreate(&b) != hipSuccess)) return 1;
+        *ev0 = a; *ev1 = b;
+        return 1 + (t->started++ & 1);
+    }
+    if (hipEventQuery(t->ev[4 * TILE_TUNE_TRIALS - 1]) != hipSuccess) return 1;      // (the timed launches are still under way)
+    float best[2] = {3.0e38f, 3.0e38f};
+    for (int i = 0; i < 2 * TILE_TUNE_TRIALS; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t->ev[2 * i], t->ev[2 * i + 1]) == hipSuccess) best[i & 1] = std::min(best[i & 1], ms);
+    }
+    t->decided = best[1] < best[0] ? 2 : 1;
+    return t->decided;
+}
+
 template <class R, bool COUNT, bool TRI_ONLY>
 int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow, bool want_counts)
 {
@@ -317,7 +385,7 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
     // the per-call counters are cleared only for a caller that reads them (an overflow is latched on the device either way)
     if (want_counts) HIP_TRY(hipMemsetAsync(ctx->counters.p, 0, sizeof(rtk::TraceCounters), ctx->stream));
     int wpb = g.threads / 64;
-    int blocks = (int)rtk::tile_grid_blocks((a.width + 7) / 8, (a.row_end - a.row_begin + 7) / 8, wpb, g.mode == rtk::TRAV_NODES, 1, rtk::tile_strata<R>());
+    int blocks = (int)rtk::tile_grid_blocks((a.width + 7) / 8, (a.row_end - a.row_begin + 7) / 8, wpb, g.mode == rtk::TRAV_NODES, 1, a.strata);
 #define RT_LAUNCH_PRIMARY(MODE)                                                                                                              \
     if ((rc = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), g.lds))) return rc;     \
     hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, \
@@ -438,6 +506,9 @@ void rt_context_destroy(rt_context* ctx)
     for (auto& ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : ctx->chunk_ev) (void)hipEventDestroy(ev);
+    for (auto& t : ctx->tile_tune)
+        for (auto& ev : t.ev)
+            if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->side) (void)hipStreamDestroy(ctx->side);
@@ -1077,6 +1148,7 @@ int upload_tree(rt_context* ctx, const HostTree& t, size_t n_objects)
     ctx->n_prims = (int)t.n_prims;
     ctx->n_objects = (int)n_objects;
     ctx->has_scene = true;
+    ctx->scene_generation++;
     return RT_OK;
 }
 }  // namespace
@@ -1268,6 +1340,7 @@ int rt_scene_upload_lbvh(rt_context* ctx, const rt_scene* scene, double* build_m
     ctx->n_prims = (int)n;
     ctx->n_objects = (int)s.objects.size();
     ctx->has_scene = true;
+    ctx->scene_generation++;
     return RT_OK;
     });
 }
@@ -1337,12 +1410,18 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
     a.width = p->width; a.height = p->height; a.row_begin = row_begin; a.row_end = row_end;
     a.shadow = p->shadow_rays == 2 ? 2 : (p->shadow_rays ? 1 : 0);
     a.band_rows = p->band_rows; a.n_parts = p->n_parts; a.part = p->part;
+    a.strata = 1;
+    hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
+    if (const char* e = getenv("RT_TILE_STRATA")) a.strata = std::max(1, std::min(16, atoi(e)));      // tuning aid (see tile_of_wave)
+    else if (!p->count_work) a.strata = tile_order_of(ctx, tile_view_key(ctx, a, p->precision), &tune_ev0, &tune_ev1);
     if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));      // (timing events only for a caller that reads them)
+    if (tune_ev0) HIP_TRY(hipEventRecord(tune_ev0, ctx->stream));
     if (p->count_work)
         rc = p->precision == RT_F64 ? launch_primary<double, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr) : launch_primary<float, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr);
     else
         rc = p->precision == RT_F64 ? launch_primary<double, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr) : launch_primary<float, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr);
     if (rc) return rc;
+    if (tune_ev1) HIP_TRY(hipEventRecord(tune_ev1, ctx->stream));
     if (stats) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
     if (stats) {
         rtk::TraceCounters c;
@@ -1357,6 +1436,7 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         stats->kernel_ms = ms;
         stats->trace_kernel_ms = ms;
+        stats->tile_strata = (uint64_t)a.strata;
     }
     return RT_OK;
     });
@@ -1793,7 +1873,7 @@ int launch_render_levels(rt_context* ctx, const rtr::RenderArgs& a, const TraceG
     const int cap = stack_cap(ctx);
     rtr::ShadeData sd{(const rtf::ObjShade*)ctx->objs.p, (const rtf::TexDesc*)ctx->texdesc.p, (const double*)ctx->texels.p};
     const int wpb = g.threads / 64;
-    const dim3 grid((unsigned)rtk::tile_grid_blocks((a.col_end - a.col_begin + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth, rtk::tile_strata<R>()));
+    const dim3 grid((unsigned)rtk::tile_grid_blocks((a.col_end - a.col_begin + 7) / 8, (rows + 7) / 8, wpb, MODE == rtk::TRAV_NODES, a.aadepth));
     int rc_lds;
     if (COUNT) {
         if ((rc_lds = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtr::render_primary_kernel<R, TRI_ONLY, MODE, false, COUNT>), g.lds))) return rc_lds;

@@ -386,6 +386,7 @@ struct PrimaryArgs {
     int width, height, row_begin, row_end;
     int shadow;
     int band_rows, n_parts, part;   // row interleave (band_rows == 0: contiguous)
+    int strata;                     // compact tile order: strata an XCD's sequence of super-blocks is taken from in turn (tile_of_wave)
 };
 
 // Which 8x8 pixel tile a wave of the pixel kernels takes; two orders, both measured.
@@ -393,17 +394,21 @@ struct PrimaryArgs {
 //    (128 x 64 pixels) walked in Morton order, so the waves of a block look at neighbouring pixels and share
 //    triangle records in L1.  Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8, each
 //    with its own L2): XCD x takes super-blocks x, x + 8, ... and finishes each before the next.  3-5 % faster
-//    than rows of tiles on the teapot frames.  An XCD's sequence of super-blocks runs down the frame, and a frame's
-//    upper and lower part are seldom alike (ceiling and far wall above, the objects and the floor below): with `strata`
-//    = 2 the sequence is taken from its first and its second half in turn, so that what is resident at any time is a
-//    mix of both.  The headline frame in double: 0.301 -> 0.283 ms; in float 2 % slower, as are 4, 8 and 16 strata in
-//    either precision (tile_strata); the two halves dealt out 4, 16 or 32 tiles at a time instead of a super-block at a
-//    time: 0.309 / 0.285 / 0.284 ms; the upper half, the lower half or both walked upward: 0.284 / 0.316 / 0.324 ms.
+//    than rows of tiles on the teapot frames.
+//    How long a launch takes depends on WHICH tiles are resident together, by more than one would think: with `strata`
+//    = 2 (tuning aid RT_TILE_STRATA) an XCD's sequence is taken from its upper and its lower half in turn, so that the
+//    frame's cheap part (ceiling, far wall) and its heavy part (objects, floor) are under way at the same time.  The
+//    headline frame in double then takes 0.283 instead of 0.301 ms (vector units 73 % busy instead of 67 %) -- and
+//    the same frame without the occlusion queries 0.151 instead of 0.128, with closest-hit shadow rays 0.367 instead of
+//    0.335, the other teapot mesh 0.311 instead of 0.291, while a camera near the floor gains 6-15 % in every form
+//    (tools/strata_sweep.py: 36 combinations of mesh, camera, shadow query and precision, -15 % to +27 %).  No rule
+//    that holds across frames came out of it (4, 8, 16 strata, the halves dealt out 4 to 32 tiles at a time, either
+//    half walked upward, two tiles per wave: each better on some frames and worse on most), so the default stays the
+//    plain sequence.
 //  * rows of tiles (large scenes): consecutive waves take consecutive tiles of a row.  On the 10 M-triangle grid
 //    the compact order lowers L1/L2 misses but leaves fewer waves resident on average (3.0 instead of 3.6 per
 //    SIMD) and the frame takes 9 % longer, so such scenes keep this order.
 constexpr int SB_TX = 16, SB_TY = 8, SB_TILES = SB_TX * SB_TY, N_XCD = 8;
-template <class R> constexpr int tile_strata() { return sizeof(R) == 8 ? 2 : 1; }
 // (`split` consecutive waves share a tile: wave `*part` of them takes that share of the tile's samples)
 __host__ __device__ inline long long tile_grid_blocks(int tiles_x, int tiles_y, int waves_per_block, bool compact, int split = 1, int strata = 1)
 {
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
     // blocks as earlier ones retire (a shared counter serves only ~90 requests per microsecond
     // chip-wide, which is fewer than the tiles this kernel retires)
     int tx, ty;
-    if (tile_of_wave<MODE == TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, 1, nullptr, tile_strata<R>())) {
+    if (tile_of_wave<MODE == TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, 1, nullptr, (unsigned)a.strata)) {
         int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
         if (x < a.width && yl < rows) {
             int yc = a.row_begin + yl;   // row in this call's (compact) row space

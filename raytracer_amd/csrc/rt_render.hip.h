@@ -138,7 +138,7 @@ __global__ __launch_bounds__(rtk::MAX_BLOCK) void render_primary_kernel(rtf::Sce
     // one 8x8 tile and one of its aadepth sample columns per wave (the waves of a tile are neighbours in a block,
     // so they share its nodes and triangles in L1); the dispatcher balances the load
     int tx, ty, aax;
-    if (rtk::tile_of_wave<MODE == rtk::TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, (unsigned)a.aadepth, &aax, rtk::tile_strata<R>())) {
+    if (rtk::tile_of_wave<MODE == rtk::TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, (unsigned)a.aadepth, &aax)) {
         // The aadepth waves of a tile share its samples.  With 2, 4 or 8 sample columns a wave takes ALL columns of a part
         // of the tile -- 8 x 4 pixels x 2, 4 x 4 pixels x 4 or a row of 8 pixels x 8 -- instead of one column of the whole
         // tile: the columns of a pixel are almost the same ray, so the wave's rays stay together for longer.

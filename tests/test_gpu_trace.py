@@ -547,3 +547,35 @@ def test_blocks_with_more_than_64k_of_lds(gpu_ctx, scenes, monkeypatch):
     assert eq(big, plain) and st_big.secondary_rays == st_plain.secondary_rays > 0
     s.emit_photons_gpu(gpu_ctx, 20000, seed=3)
     assert s.photon_count(0) == n_big > 20000 and st_emit.secondary_rays > 20000
+
+
+def test_tile_order_is_chosen_by_measurement_and_changes_no_frame(gpu_ctx, scenes, monkeypatch):
+    """The camera-ray kernel takes a frame's tiles in one of two orders; the library times both on the first launches of a view
+    and keeps the faster.  Whatever it does, the id map is the reference's: with either order fixed, during the timed
+    launches, and after it has settled; and once settled it stays settled for the view."""
+    gpu_ctx.upload(scenes["teapot_normal"])
+    cam = rt.look_at(CAM[:3], CAM[3:])
+    g = golden_hashes()["teapot_normal"]
+    p = rt.default_params(width=1920, height=1080, shadow_rays=2)
+    plain = rt.default_params(width=1920, height=1080)
+    for fixed in ("1", "2", "4"):
+        monkeypatch.setenv("RT_TILE_STRATA", fixed)
+        ids, _, _, st = gpu_ctx.trace_primary(cam, plain)
+        assert st.tile_strata == int(fixed) and id_map_hash(ids) == g["hash"]
+        folded = gpu_ctx.trace_primary(cam, p)[0]
+        assert id_map_hash(np.where(folded >= 0, folded & ~(1 << 30), folded)) == g["hash"]
+        if fixed == "1":
+            reference = folded
+        assert eq(folded, reference)
+    monkeypatch.delenv("RT_TILE_STRATA")
+    seen = []
+    for i in range(12):      # (every call here waits for its kernel, so the eight timed launches are the first eight)
+        folded, _, _, st = gpu_ctx.trace_primary(cam, p)
+        assert eq(folded, reference)
+        seen.append(int(st.tile_strata))
+    assert seen[:8] == [1, 2] * 4 and seen[8] in (1, 2) and seen[8:] == [seen[8]] * 4
+    print("tile order settled on", seen[8], "strata for the teapot frame with occlusion queries")
+    # another view is measured anew; the first one keeps its order
+    cam2 = rt.look_at((2.4, -0.8, -1.0), (0, -0.5, 0))
+    assert [int(gpu_ctx.trace_primary(cam2, p)[3].tile_strata) for _ in range(2)] == [1, 2]
+    assert int(gpu_ctx.trace_primary(cam, p)[3].tile_strata) == seen[8]

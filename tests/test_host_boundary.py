@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(raw, name), f"{name} declared in rt_amd.h but not exported"
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert _lib.lib.rt_abi_version() == 1
+    assert _lib.lib.rt_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
