@@ -379,7 +379,7 @@ def main():
         "cpu_baseline": cpu,
         "parity": parity,
         "tile_order": {"strata": tile_strata, "note": "1: an XCD takes its super-blocks of tiles down the frame; 2: from the frame's two halves in turn.  Chosen per view by the library from "
-                       "timed launches of both orders among the first eight of the view (the warm-up here); same work and same frames either way"},
+                       "timed launches of both orders, eight in all, once the view has come a second time (the warm-up here); same work and same frames either way"},
         "other_configs": extras,
         "strong_scaling": strong,
     }

@@ -102,8 +102,8 @@ typedef struct rt_stats {
     double trace_kernel_ms;   /* device time of the traversal kernel launches only */
     uint64_t gather_single;   /* of gather_queries: answered one per wave (subsurface hits, groups the grouped form handed over) */
     uint64_t tile_strata;     /* rt_trace_primary*: the order this launch took the frame's tiles in -- 1: the plain sequence, 2: from the
-                               * frame's two halves in turn; the library measures both on the first launches of a view and keeps the
-                               * faster (same frames either way).  0 from the other entry points */
+                               * frame's two halves in turn; the library measures both on the first launches of a view that repeats and
+                               * keeps the faster (same frames either way).  0 from the other entry points */
 } rt_stats;
 
 /* ---- process / context ------------------------------------------------------------------- */

@@ -138,10 +138,11 @@ struct rt_scene {
 
 // The order in which the camera-ray kernel takes a frame's tiles, chosen by measurement per view (see tile_order_of): which
 // of the two orders a launch of this frame used when it was timed, how long it took, and which one has won.
-constexpr int TILE_TUNE_ENTRIES = 8, TILE_TUNE_TRIALS = 4;
+constexpr int TILE_TUNE_ENTRIES = 32, TILE_TUNE_TRIALS = 4;
 struct TileTune {
     uint64_t key = 0;                    // of scene, camera, frame and query
     int decided = 0;                     // 0: still measuring; else the number of strata (1 or 2)
+    int seen = 0;                        // launches of the view so far (the first is not yet a trial: a camera that moves never comes back)
     int started = 0;                     // timed launches begun: launch i runs between ev[2 i] and ev[2 i + 1] with 1 + i % 2 strata
     hipEvent_t ev[4 * TILE_TUNE_TRIALS] = {};
     uint64_t used = 0;                   // for replacement: the least recently used entry goes
@@ -323,8 +324,8 @@ int launch_batch(rt_context* ctx, int64_t n, const double* d_org, const double* 
 
 // How long the camera-ray kernel takes depends on which tiles are under way together (rtk::tile_of_wave), by 5-25 % between
 // the plain sequence and the one taken from the frame's two halves in turn, and which of the two is the faster depends on
-// the view.  So it is measured: the first 2 x TILE_TUNE_TRIALS launches of a view -- same scene, camera, frame and query --
-// alternate between the two orders, each inside its own pair of events; the launches after them take the plain order until
+// the view.  So it is measured: once a view -- same scene, camera, frame and query -- comes a second time, its next
+// 2 x TILE_TUNE_TRIALS launches alternate between the two orders, each inside its own pair of events; the launches after them take the plain order until
 // the last of those has finished (nobody waits: a caller that enqueues ahead of the device just stays with the plain order
 // a little longer), and from then on the order with the shortest launch is the view's.  RT_TILE_STRATA=<n> fixes the order
 // instead.  The frames are the same either way.
@@ -354,10 +355,11 @@ int tile_order_of(rt_context* ctx, uint64_t key, hipEvent_t* ev0, hipEvent_t* ev
         t = oldest;
         // (its events are about to be recorded anew: the launches they belong to have to be past them)
         if (!t->decided && t->started > 0 && hipEventSynchronize(t->ev[2 * t->started - 1]) != hipSuccess) return 1;
-        t->key = key; t->decided = 0; t->started = 0;
+        t->key = key; t->decided = 0; t->started = 0; t->seen = 0;
     }
     t->used = ++ctx->tile_tune_clock;
     if (t->decided) return t->decided;
+    if (t->seen++ == 0) return 1;      // (a view seen once is not worth measuring: frames of a moving camera all take the plain order)
     if (t->started < 2 * TILE_TUNE_TRIALS) {
         hipEvent_t& a = t->ev[2 * t->started];
         hipEvent_t& b = t->ev[2 * t->started + 1];

@@ -569,13 +569,16 @@ def test_tile_order_is_chosen_by_measurement_and_changes_no_frame(gpu_ctx, scene
         assert eq(folded, reference)
     monkeypatch.delenv("RT_TILE_STRATA")
     seen = []
-    for i in range(12):      # (every call here waits for its kernel, so the eight timed launches are the first eight)
+    for i in range(13):      # (every call here waits for its kernel: the view's first launch, then the eight timed ones)
         folded, _, _, st = gpu_ctx.trace_primary(cam, p)
         assert eq(folded, reference)
         seen.append(int(st.tile_strata))
-    assert seen[:8] == [1, 2] * 4 and seen[8] in (1, 2) and seen[8:] == [seen[8]] * 4
-    print("tile order settled on", seen[8], "strata for the teapot frame with occlusion queries")
-    # another view is measured anew; the first one keeps its order
+    assert seen[:9] == [1] + [1, 2] * 4 and seen[9] in (1, 2) and seen[9:] == [seen[9]] * 4
+    print("tile order settled on", seen[9], "strata for the teapot frame with occlusion queries")
+    # another view is measured anew, from its second launch on; the first one keeps its order; a camera that moves stays plain
     cam2 = rt.look_at((2.4, -0.8, -1.0), (0, -0.5, 0))
-    assert [int(gpu_ctx.trace_primary(cam2, p)[3].tile_strata) for _ in range(2)] == [1, 2]
-    assert int(gpu_ctx.trace_primary(cam, p)[3].tile_strata) == seen[8]
+    assert [int(gpu_ctx.trace_primary(cam2, p)[3].tile_strata) for _ in range(4)] == [1, 1, 2, 1]
+    assert int(gpu_ctx.trace_primary(cam, p)[3].tile_strata) == seen[9]
+    for i in range(1, 7):
+        moving = rt.look_at((2.4 + 0.01 * i, -0.8, -1.0), (0, -0.5, 0))
+        assert int(gpu_ctx.trace_primary(moving, p)[3].tile_strata) == 1
