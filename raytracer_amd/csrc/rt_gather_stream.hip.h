@@ -780,338 +780,338 @@ __device__ __forceinline__ void gather_stream_body(const PhotonMapView& pm, cons
         float vol_r_here = -1.f, vol_cx = 0.f, vol_cy = 0.f, vol_cz = 0.f;      // the last volume round of this window: its centre and k-th distance
         double surf0 = 0, surf1 = 0, surf2 = 0, vol0 = 0, vol1 = 0, vol2 = 0;
         for (int phase = 0; phase < (SSS ? 4 : 1); phase++) {
-        const bool volume = SSS && phase > 0;
-        double e_pass = 1.0;                        // e^pass of main.cpp:371
-        if (volume) {
-            // phase 1: around the hit point (main.cpp:310); 2 and 3: the march of main.cpp:337-376, where refraction is possible
-            const bool in_phase = volume_here && sss_wait && !redo && vm.n > 0 && vm.n < (1ll << 24) && (phase == 1 || (flags & GATHER_MARCH) != 0);
-            if (!__ballot(in_phase)) break;
-            todo = in_phase;
-            if (phase >= 2) {
-                double px = r.pos[0] + r.march[0] * 0.02, py = r.pos[1] + r.march[1] * 0.02, pz = r.pos[2] + r.march[2] * 0.02;      // main.cpp:341
-                e_pass = 2.71828;
-                if (phase == 3) {
-                    // (the step length as answer_request draws it: keyed by pixel, hit point and pass)
-                    const uint32_t where = __float_as_uint(hx) * 0x9E3779B1u ^ __float_as_uint(hy) * 0x85EBCA77u ^ __float_as_uint(hz) * 0xC2B2AE3Du;
-                    const double d = -log(unit_random(r.pixel, where + 1u, gp.seed)) / 200;      // main.cpp:374
-                    px += r.march[0] * d; py += r.march[1] * d; pz += r.march[2] * d;
-                    e_pass *= 2.71828;
+            const bool volume = SSS && phase > 0;
+            double e_pass = 1.0;                        // e^pass of main.cpp:371
+            if (volume) {
+                // phase 1: around the hit point (main.cpp:310); 2 and 3: the march of main.cpp:337-376, where refraction is possible
+                const bool in_phase = volume_here && sss_wait && !redo && vm.n > 0 && vm.n < (1ll << 24) && (phase == 1 || (flags & GATHER_MARCH) != 0);
+                if (!__ballot(in_phase)) break;
+                todo = in_phase;
+                if (phase >= 2) {
+                    double px = r.pos[0] + r.march[0] * 0.02, py = r.pos[1] + r.march[1] * 0.02, pz = r.pos[2] + r.march[2] * 0.02;      // main.cpp:341
+                    e_pass = 2.71828;
+                    if (phase == 3) {
+                        // (the step length as answer_request draws it: keyed by pixel, hit point and pass)
+                        const uint32_t where = __float_as_uint(hx) * 0x9E3779B1u ^ __float_as_uint(hy) * 0x85EBCA77u ^ __float_as_uint(hz) * 0xC2B2AE3Du;
+                        const double d = -log(unit_random(r.pixel, where + 1u, gp.seed)) / 200;      // main.cpp:374
+                        px += r.march[0] * d; py += r.march[1] * d; pz += r.march[2] * d;
+                        e_pass *= 2.71828;
+                    }
+                    qx = (float)px; qy = (float)py; qz = (float)pz;
                 }
-                qx = (float)px; qy = (float)py; qz = (float)pz;
             }
-        }
-        const PhotonMapView& map = volume ? vm : pm;
-        for (int round = (phase == 0 ? round_first : 0); round < ROUNDS; round++) {
-            const unsigned long long m_todo = __ballot(todo);
-            if (!m_todo) break;
-            // ---- the round's centre: the middle one of the requests waiting
-            int c_lane = 0;
-            {
-                const int want_rank = __builtin_popcountll(m_todo) / 2;
-                unsigned long long mm = m_todo;
-                for (int i = 0; i < want_rank; i++) mm &= mm - 1;
-                c_lane = __builtin_ctzll(mm);
-            }
-            const float cx = bcast(qx, c_lane), cy = bcast(qy, c_lane), cz = bcast(qz, c_lane);
-            const float ddx = qx - cx, ddy = qy - cy, ddz = qz - cz;
-            const float d_c = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
-            // a first look at who is near, with the radius unknown: if only a few are within the widest possible ball they
-            // are not worth a round of their own
-            const bool near = todo && d_c <= r_max;
-            if (__builtin_popcountll(__ballot(near)) < MIN_LANES) {
-                TILE_COUNT(TP_R_FEW, near);
-                redo = redo || near;
-                todo = todo && !near;
-                continue;
-            }
-            // A window of subsurface requests is one wave's from its first phase to its last, and the longest such window is the
-            // least the kernel takes: past S_SSS_TRIES rounds (four phases of one round each is the common case, of two across a
-            // silhouette), or S_SSS_STEPS steps of 64 photons streamed by a pass (120 in the common case; several times that where
-            // the balls are wide -- the unlit side of an object, whose few photons lie far apart), what still waits goes to the
-            // per-request kernel, which spreads it over as many waves as there are requests.
-            if (keep_whole && (++tries > S_SSS_TRIES || work > S_SSS_STEPS)) {
-                TILE_COUNT(TP_R_LEFT, todo);
-                redo = redo || todo;
-                todo = false;
-                break;
-            }
-            // ---- 1. the centre's k-th distance r_c (< 0: fewer than k photons within the search radius)
-            float r_c = -1.f, R_found = 0.f;
-            int n_pack = 0;
-            bool found = false;
-            {
-                const unsigned long long t_kth = PROF ? clock64() : 0ull;
-                // The guess only has to be within a factor of a few: the photons actually counted inside it correct it
-                // (density ~ count / R^2 on a surface), so a second walk, where one is needed, starts from a good radius.
-                float guess;
-                if (volume && phase >= 2 && vol_r_here > 0.f) {
-                    // (the march moves the centre a few hundredths: the radius found a phase ago, and what the move can add)
-                    const float mx = cx - vol_cx, my = cy - vol_cy, mz = cz - vol_cz;
-                    guess = (vol_r_here + sqrtf(mx * mx + my * my + mz * mz)) * 1.02f;
-                } else {
-                    TILE_PROF(TP_C_GUESS, guess = radius_guess(map, cx, cy, cz, gp.k, volume) * 1.15f);
+            const PhotonMapView& map = volume ? vm : pm;
+            for (int round = (phase == 0 ? round_first : 0); round < ROUNDS; round++) {
+                const unsigned long long m_todo = __ballot(todo);
+                if (!m_todo) break;
+                // ---- the round's centre: the middle one of the requests waiting
+                int c_lane = 0;
+                {
+                    const int want_rank = __builtin_popcountll(m_todo) / 2;
+                    unsigned long long mm = m_todo;
+                    for (int i = 0; i < want_rank; i++) mm &= mm - 1;
+                    c_lane = __builtin_ctzll(mm);
                 }
-                const float prev = volume ? prev_r_vol : prev_r;
-                if (!(guess > 0.f)) { guess = prev > 0.f ? prev * 1.2f : r_max * 0.3f; if (PROF) pr[TP_A_NOGUESS]++; }
-                float too_small = 0.f, too_large = 3.0e38f;      // radii that held fewer than k photons / overflowed the lists
-                for (int attempt = 0; attempt < (volume ? S_ATTEMPTS_VOLUME : S_ATTEMPTS) && !found; attempt++) {
-                    if (PROF) pr[TP_N_HIST]++;
-                    // (a subsurface window: no more than S_SSS_ATTEMPTS walks, all its rounds together -- where the balls are so wide
-                    // that the lists barely hold them every walk is a long one, and a failed round costs several)
-                    if (keep_whole && ++w_attempts > S_SSS_ATTEMPTS) break;
-                    const float R = fminf(guess, r_max);
-                    const bool whole = !(R < r_max);                            // the search radius itself: nothing larger to try
-                    const bool cand = near && d_c <= R;                         // who can be in the round if r_c <= R
-                    // every such request's ball lies within its point +- rad (its bound never exceeds the search radius)
-                    const float rad = fminf(R * (1.f + gp.opt_range) * 1.002f + 1e-5f, r_max * 1.0002f + 2e-6f);
-                    const float big = 3.0e38f;
-                    const float glx = wave_min_f(cand ? qx - rad : big), gly = wave_min_f(cand ? qy - rad : big), glz = wave_min_f(cand ? qz - rad : big);
-                    const float ghx = wave_max_f(cand ? qx + rad : -big), ghy = wave_max_f(cand ? qy + rad : -big), ghz = wave_max_f(cand ? qz + rad : -big);
-                    const float reach = wave_max_f(cand ? d_c : 0.f) + rad;
-                    __builtin_amdgcn_wave_barrier();
-                    int lists;
-                    TILE_PROF(TP_C_WALK, lists = stream_walk(map, glx, gly, glz, ghx, ghy, ghz, cx, cy, cz, reach * reach * 1.0001f));
-                    if (lists < 0) {
-                        if (PROF) pr[TP_A_LISTS]++;
-                        // too much of the tree: a smaller radius, unless that is known to hold fewer than k photons
-                        too_large = fminf(too_large, R);
-                        // (the photons in reach go with the radius squared on a surface, cubed in a volume: a smaller step back there)
-                        guess = fmaxf(R * (volume ? 0.8f : 0.6f), sqrtf(too_small * R));
-                        if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
-                        continue;
+                const float cx = bcast(qx, c_lane), cy = bcast(qy, c_lane), cz = bcast(qz, c_lane);
+                const float ddx = qx - cx, ddy = qy - cy, ddz = qz - cz;
+                const float d_c = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+                // a first look at who is near, with the radius unknown: if only a few are within the widest possible ball they
+                // are not worth a round of their own
+                const bool near = todo && d_c <= r_max;
+                if (__builtin_popcountll(__ballot(near)) < MIN_LANES) {
+                    TILE_COUNT(TP_R_FEW, near);
+                    redo = redo || near;
+                    todo = todo && !near;
+                    continue;
+                }
+                // A window of subsurface requests is one wave's from its first phase to its last, and the longest such window is the
+                // least the kernel takes: past S_SSS_TRIES rounds (four phases of one round each is the common case, of two across a
+                // silhouette), or S_SSS_STEPS steps of 64 photons streamed by a pass (120 in the common case; several times that where
+                // the balls are wide -- the unlit side of an object, whose few photons lie far apart), what still waits goes to the
+                // per-request kernel, which spreads it over as many waves as there are requests.
+                if (keep_whole && (++tries > S_SSS_TRIES || work > S_SSS_STEPS)) {
+                    TILE_COUNT(TP_R_LEFT, todo);
+                    redo = redo || todo;
+                    todo = false;
+                    break;
+                }
+                // ---- 1. the centre's k-th distance r_c (< 0: fewer than k photons within the search radius)
+                float r_c = -1.f, R_found = 0.f;
+                int n_pack = 0;
+                bool found = false;
+                {
+                    const unsigned long long t_kth = PROF ? clock64() : 0ull;
+                    // The guess only has to be within a factor of a few: the photons actually counted inside it correct it
+                    // (density ~ count / R^2 on a surface), so a second walk, where one is needed, starts from a good radius.
+                    float guess;
+                    if (volume && phase >= 2 && vol_r_here > 0.f) {
+                        // (the march moves the centre a few hundredths: the radius found a phase ago, and what the move can add)
+                        const float mx = cx - vol_cx, my = cy - vol_cy, mz = cz - vol_cz;
+                        guess = (vol_r_here + sqrtf(mx * mx + my * my + mz * mz)) * 1.02f;
+                    } else {
+                        TILE_PROF(TP_C_GUESS, guess = radius_guess(map, cx, cy, cz, gp.k, volume) * 1.15f);
                     }
-                    const int n_leaf = lists & 0xFFFF, n_piv = lists >> 16;
-                    const float lim = whole ? gp.r2 : R * R;
-                    int packed, inside = 0;
-                    TILE_PROF(TP_C_PACK, packed = pack_listed(map.pos, pack, ta.pack_cap, cx, cy, cz, reach * reach * 1.0001f, lim, n_leaf, n_piv, &inside));
-                    __builtin_amdgcn_wave_barrier();
-                    if (packed < 0) {
-                        if (PROF) pr[TP_A_PACK]++;
-                        too_large = fminf(too_large, R);
-                        guess = fmaxf(R * (volume ? 0.85f : 0.7f), sqrtf(too_small * R));
-                        if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
-                        continue;
-                    }
-                    if (inside < gp.k && !whole) {
-                        // too few: the radius that would hold k at the density just counted, and a margin
-                        if (PROF) pr[TP_A_FEW]++;
-                        too_small = fmaxf(too_small, R);
-                        const float ratio = (float)gp.k / (float)(inside > 0 ? inside : 1);
-                        const float grow = (volume ? cbrtf(ratio) : sqrtf(ratio)) * 1.15f;      // (the count grows with the radius squared on a surface, cubed in a volume)
-                        guess = fminf(R * fminf(grow, 3.f), too_large < 3.0e38f ? sqrtf(R * too_large) : 3.0e38f);
-                        if (guess >= too_large * 0.98f || guess <= R * 1.02f) break;
-                        continue;
-                    }
-                    if (PROF && inside > 2 * gp.k) pr[TP_A_MANY]++;      // (more than needed: the filter below cuts the list down)
-                    uint32_t bits = 0;
-                    if (inside >= gp.k) {
-                        TILE_PROF(TP_C_KTH, bits = centre_select(pack, packed, cx, cy, cz, lim, gp.k));
-                        if (bits == 0xFFFFFFFFu) {
-                            int total = 0;
-                            bits = centre_kth(pack, packed, cx, cy, cz, lim, gp.k, &total);
-                        }
+                    const float prev = volume ? prev_r_vol : prev_r;
+                    if (!(guess > 0.f)) { guess = prev > 0.f ? prev * 1.2f : r_max * 0.3f; if (PROF) pr[TP_A_NOGUESS]++; }
+                    float too_small = 0.f, too_large = 3.0e38f;      // radii that held fewer than k photons / overflowed the lists
+                    for (int attempt = 0; attempt < (volume ? S_ATTEMPTS_VOLUME : S_ATTEMPTS) && !found; attempt++) {
+                        if (PROF) pr[TP_N_HIST]++;
+                        // (a subsurface window: no more than S_SSS_ATTEMPTS walks, all its rounds together -- where the balls are so wide
+                        // that the lists barely hold them every walk is a long one, and a failed round costs several)
+                        if (keep_whole && ++w_attempts > S_SSS_ATTEMPTS) break;
+                        const float R = fminf(guess, r_max);
+                        const bool whole = !(R < r_max);                            // the search radius itself: nothing larger to try
+                        const bool cand = near && d_c <= R;                         // who can be in the round if r_c <= R
+                        // every such request's ball lies within its point +- rad (its bound never exceeds the search radius)
+                        const float rad = fminf(R * (1.f + gp.opt_range) * 1.002f + 1e-5f, r_max * 1.0002f + 2e-6f);
+                        const float big = 3.0e38f;
+                        const float glx = wave_min_f(cand ? qx - rad : big), gly = wave_min_f(cand ? qy - rad : big), glz = wave_min_f(cand ? qz - rad : big);
+                        const float ghx = wave_max_f(cand ? qx + rad : -big), ghy = wave_max_f(cand ? qy + rad : -big), ghz = wave_max_f(cand ? qz + rad : -big);
+                        const float reach = wave_max_f(cand ? d_c : 0.f) + rad;
                         __builtin_amdgcn_wave_barrier();
-                    }
-                    n_pack = packed;
-                    found = true;
-                    R_found = R;
-                    r_c = inside >= gp.k ? sqrtf(__uint_as_float(bits)) : -1.f;      // (fewer than k: only within the search radius itself)
-                }
-                if (PROF) pr[TP_KTH] += clock64() - t_kth;
-            }
-            if (!found) {      // the lists cannot hold what the centre's ball touches
-                TILE_COUNT(TP_R_WALK, near);
-                redo = redo || near;
-                todo = todo && !near;
-                continue;
-            }
-            bool act = near;
-            float bound = gp.r2, lower = 0.f;
-            if (r_c >= 0.f) {
-                if (volume) { prev_r_vol = r_c; vol_r_here = r_c; vol_cx = cx; vol_cy = cy; vol_cz = cz; } else prev_r = r_c;
-                // this round: the requests inside the centre's own ball and a little beyond, as far as the packed list reaches
-                act = todo && d_c <= fminf(r_c * gp.act_reach, R_found);
-                // r_k(q) lies within |q - q_c| of r_c (triangle inequality).  For a request far from the centre that
-                // range is wide while the photon density, and with it r_k, changes little over a ball's width: such a
-                // request is given the range r_c * (1 -+ opt_range) instead.  Both ends are checked by the counts below
-                // (k photons inside the outer radius, fewer than k inside the inner one); a request that fails either
-                // goes to the per-request kernel.
-                const float dd = fminf(d_c, gp.opt_range * r_c);
-                const float reach = r_c + dd;
-                const float b = reach * reach * 1.001f + 1e-12f;      // slack for the rounding of the distances
-                if (b < bound) {
-                    bound = b;
-                    // and r_k(q) >= r_c - |q - q_c|: closer photons belong to the set whatever their order
-                    const float inner = fmaxf(r_c - dd, 0.f);
-                    lower = inner * inner * 0.999f;
-                }
-            }
-            if (__builtin_popcountll(__ballot(act)) < MIN_LANES) {
-                // (the centre itself is always among them, so every round retires at least one request)
-                TILE_COUNT(TP_R_FEW, act);
-                redo = redo || act;
-                todo = todo && !act;
-                continue;
-            }
-            todo = todo && !act;
-            // The requests still waiting become a part of their own, for whichever wave is free first (this one, if none is
-            // sooner): a window of several patches -- a tile across a silhouette -- is then worked on by several waves at once
-            // instead of holding one wave, and the kernel's end, for several rounds.  What a round computes depends on the
-            // window and the lanes waiting alone, so the results do not depend on who takes the part.
-            {
-                const unsigned long long m_left = __ballot(todo);
-                if (sharing && m_left && round + 1 < ROUNDS && !keep_whole) {
-                    unsigned long long at = ~0ull;
-                    if (lane == 0) {
-                        at = atomicAdd(my_cont + 2, 1ull);
-                        if (at < ta.cont_cap) {
-                            // (one part more to finish before the window counts as done: noted before this part is)
-                            atomicAdd(ta.windows_done, ~0ull);
-                            __hip_atomic_store(my_cont + 4 + 2 * at, m_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            __hip_atomic_store(my_cont + 5 + 2 * at, (unsigned long long)win | ((unsigned long long)(round + 1) << 32) | (1ull << 63), __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                            atomicAdd(my_cont + 1, 1ull);
+                        int lists;
+                        TILE_PROF(TP_C_WALK, lists = stream_walk(map, glx, gly, glz, ghx, ghy, ghz, cx, cy, cz, reach * reach * 1.0001f));
+                        if (lists < 0) {
+                            if (PROF) pr[TP_A_LISTS]++;
+                            // too much of the tree: a smaller radius, unless that is known to hold fewer than k photons
+                            too_large = fminf(too_large, R);
+                            // (the photons in reach go with the radius squared on a surface, cubed in a volume: a smaller step back there)
+                            guess = fmaxf(R * (volume ? 0.8f : 0.6f), sqrtf(too_small * R));
+                            if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
+                            continue;
                         }
+                        const int n_leaf = lists & 0xFFFF, n_piv = lists >> 16;
+                        const float lim = whole ? gp.r2 : R * R;
+                        int packed, inside = 0;
+                        TILE_PROF(TP_C_PACK, packed = pack_listed(map.pos, pack, ta.pack_cap, cx, cy, cz, reach * reach * 1.0001f, lim, n_leaf, n_piv, &inside));
+                        __builtin_amdgcn_wave_barrier();
+                        if (packed < 0) {
+                            if (PROF) pr[TP_A_PACK]++;
+                            too_large = fminf(too_large, R);
+                            guess = fmaxf(R * (volume ? 0.85f : 0.7f), sqrtf(too_small * R));
+                            if (guess <= too_small * 1.02f || guess >= R * 0.98f) break;
+                            continue;
+                        }
+                        if (inside < gp.k && !whole) {
+                            // too few: the radius that would hold k at the density just counted, and a margin
+                            if (PROF) pr[TP_A_FEW]++;
+                            too_small = fmaxf(too_small, R);
+                            const float ratio = (float)gp.k / (float)(inside > 0 ? inside : 1);
+                            const float grow = (volume ? cbrtf(ratio) : sqrtf(ratio)) * 1.15f;      // (the count grows with the radius squared on a surface, cubed in a volume)
+                            guess = fminf(R * fminf(grow, 3.f), too_large < 3.0e38f ? sqrtf(R * too_large) : 3.0e38f);
+                            if (guess >= too_large * 0.98f || guess <= R * 1.02f) break;
+                            continue;
+                        }
+                        if (PROF && inside > 2 * gp.k) pr[TP_A_MANY]++;      // (more than needed: the filter below cuts the list down)
+                        uint32_t bits = 0;
+                        if (inside >= gp.k) {
+                            TILE_PROF(TP_C_KTH, bits = centre_select(pack, packed, cx, cy, cz, lim, gp.k));
+                            if (bits == 0xFFFFFFFFu) {
+                                int total = 0;
+                                bits = centre_kth(pack, packed, cx, cy, cz, lim, gp.k, &total);
+                            }
+                            __builtin_amdgcn_wave_barrier();
+                        }
+                        n_pack = packed;
+                        found = true;
+                        R_found = R;
+                        r_c = inside >= gp.k ? sqrtf(__uint_as_float(bits)) : -1.f;      // (fewer than k: only within the search radius itself)
                     }
-                    at = bcast64(at, 0);
-                    if (at < ta.cont_cap) todo = false;      // (a full list: the rounds stay here)
+                    if (PROF) pr[TP_KTH] += clock64() - t_kth;
                 }
-            }
-            // ---- 2. the packed list cut down to the box around the round's balls and the centre's reach: what it holds now
-            // depends on the window alone
-            {
-                const float rad = act ? sqrtf(bound) * 1.0001f + 1e-6f : 0.f;
-                const float big = 3.0e38f;
-                Box6f bx;
-                bx.lx = wave_min_f(act ? qx - rad : big); bx.ly = wave_min_f(act ? qy - rad : big); bx.lz = wave_min_f(act ? qz - rad : big);
-                bx.hx = wave_max_f(act ? qx + rad : -big); bx.hy = wave_max_f(act ? qy + rad : -big); bx.hz = wave_max_f(act ? qz + rad : -big);
-                const float reach = wave_max_f(act ? d_c + rad : 0.f);
-                if (PROF) pr[TP_N_CRIT] += n_pack;
-                TILE_PROF(TP_WALK, n_pack = pack_refilter(pack, n_pack, cx, cy, cz, reach * reach * 1.0001f, bx));
-                __builtin_amdgcn_wave_barrier();
-            }
-            const int n_steps = (n_pack + WAVE - 1) / WAVE;
-            work += n_steps;
-            rounds_done++;
-            if (PROF) pr[TP_ROUNDS]++; if (PROF) pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_steps; if (PROF) pr[TP_N_SUM] += n_pack;
+                if (!found) {      // the lists cannot hold what the centre's ball touches
+                    TILE_COUNT(TP_R_WALK, near);
+                    redo = redo || near;
+                    todo = todo && !near;
+                    continue;
+                }
+                bool act = near;
+                float bound = gp.r2, lower = 0.f;
+                if (r_c >= 0.f) {
+                    if (volume) { prev_r_vol = r_c; vol_r_here = r_c; vol_cx = cx; vol_cy = cy; vol_cz = cz; } else prev_r = r_c;
+                    // this round: the requests inside the centre's own ball and a little beyond, as far as the packed list reaches
+                    act = todo && d_c <= fminf(r_c * gp.act_reach, R_found);
+                    // r_k(q) lies within |q - q_c| of r_c (triangle inequality).  For a request far from the centre that
+                    // range is wide while the photon density, and with it r_k, changes little over a ball's width: such a
+                    // request is given the range r_c * (1 -+ opt_range) instead.  Both ends are checked by the counts below
+                    // (k photons inside the outer radius, fewer than k inside the inner one); a request that fails either
+                    // goes to the per-request kernel.
+                    const float dd = fminf(d_c, gp.opt_range * r_c);
+                    const float reach = r_c + dd;
+                    const float b = reach * reach * 1.001f + 1e-12f;      // slack for the rounding of the distances
+                    if (b < bound) {
+                        bound = b;
+                        // and r_k(q) >= r_c - |q - q_c|: closer photons belong to the set whatever their order
+                        const float inner = fmaxf(r_c - dd, 0.f);
+                        lower = inner * inner * 0.999f;
+                    }
+                }
+                if (__builtin_popcountll(__ballot(act)) < MIN_LANES) {
+                    // (the centre itself is always among them, so every round retires at least one request)
+                    TILE_COUNT(TP_R_FEW, act);
+                    redo = redo || act;
+                    todo = todo && !act;
+                    continue;
+                }
+                todo = todo && !act;
+                // The requests still waiting become a part of their own, for whichever wave is free first (this one, if none is
+                // sooner): a window of several patches -- a tile across a silhouette -- is then worked on by several waves at once
+                // instead of holding one wave, and the kernel's end, for several rounds.  What a round computes depends on the
+                // window and the lanes waiting alone, so the results do not depend on who takes the part.
+                {
+                    const unsigned long long m_left = __ballot(todo);
+                    if (sharing && m_left && round + 1 < ROUNDS && !keep_whole) {
+                        unsigned long long at = ~0ull;
+                        if (lane == 0) {
+                            at = atomicAdd(my_cont + 2, 1ull);
+                            if (at < ta.cont_cap) {
+                                // (one part more to finish before the window counts as done: noted before this part is)
+                                atomicAdd(ta.windows_done, ~0ull);
+                                __hip_atomic_store(my_cont + 4 + 2 * at, m_left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                __hip_atomic_store(my_cont + 5 + 2 * at, (unsigned long long)win | ((unsigned long long)(round + 1) << 32) | (1ull << 63), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                                atomicAdd(my_cont + 1, 1ull);
+                            }
+                        }
+                        at = bcast64(at, 0);
+                        if (at < ta.cont_cap) todo = false;      // (a full list: the rounds stay here)
+                    }
+                }
+                // ---- 2. the packed list cut down to the box around the round's balls and the centre's reach: what it holds now
+                // depends on the window alone
+                {
+                    const float rad = act ? sqrtf(bound) * 1.0001f + 1e-6f : 0.f;
+                    const float big = 3.0e38f;
+                    Box6f bx;
+                    bx.lx = wave_min_f(act ? qx - rad : big); bx.ly = wave_min_f(act ? qy - rad : big); bx.lz = wave_min_f(act ? qz - rad : big);
+                    bx.hx = wave_max_f(act ? qx + rad : -big); bx.hy = wave_max_f(act ? qy + rad : -big); bx.hz = wave_max_f(act ? qz + rad : -big);
+                    const float reach = wave_max_f(act ? d_c + rad : 0.f);
+                    if (PROF) pr[TP_N_CRIT] += n_pack;
+                    TILE_PROF(TP_WALK, n_pack = pack_refilter(pack, n_pack, cx, cy, cz, reach * reach * 1.0001f, bx));
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const int n_steps = (n_pack + WAVE - 1) / WAVE;
+                work += n_steps;
+                rounds_done++;
+                if (PROF) pr[TP_ROUNDS]++; if (PROF) pr[TP_LANES] += __builtin_popcountll(__ballot(act)); pr[TP_STEPS] += n_steps; if (PROF) pr[TP_N_SUM] += n_pack;
 
-            const Shell sh = shell_of(bound, lower);
-            const float radius2 = act && !(bound < gp.r2) ? gp.r2 : 3.0e38f;      // lanes bounded by the search radius itself
-            const bool any_radius = __ballot(radius2 < 3.0e38f) != 0;
-            // ---- 3a. per-lane histogram of the squared distances below the lane's bound
-            if (any_radius) TILE_PROF(TP_HIST, stream_hist<true>(pack, n_pack, qx, qy, qz, sh, radius2));
-            else TILE_PROF(TP_HIST, stream_hist<false>(pack, n_pack, qx, qy, qz, sh, radius2));
-            uint32_t* const mine = hist_mine(cell, lane);
-            // the bin holding the lane's k-th smallest distance (or its largest, if fewer than k lie within the bound)
-            uint32_t total = 0;                                   // (the last bin holds what lies beyond the bound)
-#pragma unroll 4
-            for (int b = 0; b < T_BINS - 1; b++) total += hist_count(mine, lane, b);
-            const uint32_t k_eff = total < (uint32_t)gp.k ? total : (uint32_t)gp.k;
-            // a bound derived from the neighbour must contain k photons; if it does not, the per-request kernel decides
-            TILE_COUNT(TP_R_SHORT, act && total < (uint32_t)gp.k && bound < gp.r2);
-            if (act && total < (uint32_t)gp.k && bound < gp.r2) { redo = true; act = false; }
-            int crit = -1;
-            uint32_t below = 0, in_bin = 0;
-            {
-                uint32_t cum = 0;
-#pragma unroll 4
-                for (int b = 0; b < T_BINS - 1; b++) {
-                    const uint32_t h = hist_count(mine, lane, b);
-                    if (crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
-                    cum += h;
+                const Shell sh = shell_of(bound, lower);
+                const float radius2 = act && !(bound < gp.r2) ? gp.r2 : 3.0e38f;      // lanes bounded by the search radius itself
+                const bool any_radius = __ballot(radius2 < 3.0e38f) != 0;
+                // ---- 3a. per-lane histogram of the squared distances below the lane's bound
+                if (any_radius) TILE_PROF(TP_HIST, stream_hist<true>(pack, n_pack, qx, qy, qz, sh, radius2));
+                else TILE_PROF(TP_HIST, stream_hist<false>(pack, n_pack, qx, qy, qz, sh, radius2));
+                uint32_t* const mine = hist_mine(cell, lane);
+                // the bin holding the lane's k-th smallest distance (or its largest, if fewer than k lie within the bound)
+                uint32_t total = 0;                                   // (the last bin holds what lies beyond the bound)
+    #pragma unroll 4
+                for (int b = 0; b < T_BINS - 1; b++) total += hist_count(mine, lane, b);
+                const uint32_t k_eff = total < (uint32_t)gp.k ? total : (uint32_t)gp.k;
+                // a bound derived from the neighbour must contain k photons; if it does not, the per-request kernel decides
+                TILE_COUNT(TP_R_SHORT, act && total < (uint32_t)gp.k && bound < gp.r2);
+                if (act && total < (uint32_t)gp.k && bound < gp.r2) { redo = true; act = false; }
+                int crit = -1;
+                uint32_t below = 0, in_bin = 0;
+                {
+                    uint32_t cum = 0;
+    #pragma unroll 4
+                    for (int b = 0; b < T_BINS - 1; b++) {
+                        const uint32_t h = hist_count(mine, lane, b);
+                        if (crit < 0 && k_eff > 0 && cum + h >= k_eff) { crit = b; below = cum; in_bin = h; }
+                        cum += h;
+                    }
                 }
-            }
-            // (k photons already inside the inner radius: the range was guessed too high -- the rigorous range never is)
-            const bool crowded = act && k_eff > 0 && (in_bin > (uint32_t)T_CRIT || crit == 0);
-            TILE_COUNT(TP_R_CROWD, crowded);
-            if (crowded) { redo = true; act = false; }
-            const bool some = act && k_eff > 0;
-            const int need = (int)(k_eff - below);                 // 1-based rank of the k-th smallest inside its bin
-            __builtin_amdgcn_wave_barrier();
-            // ---- 3b. the distances of that bin, ranked
-            int cnt;
-            if (any_radius) TILE_PROF(TP_CRIT, cnt = stream_crit<true>(pack, n_pack, qx, qy, qz, sh, radius2, some ? crit : -1));
-            else TILE_PROF(TP_CRIT, cnt = stream_crit<false>(pack, n_pack, qx, qy, qz, sh, radius2, some ? crit : -1));
-            const unsigned long long t_rank = PROF ? clock64() : 0ull;
-            const int max_cnt = (int)wave_max_f((float)cnt);
-            uint32_t t_bits = 0;
-            for (int i0 = 0; i0 < max_cnt; i0 += 8) {
-                // eight entries in registers per sweep over the lane's column
-                uint32_t e[8];
-                int rank[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) { e[u] = cell[(i0 + u < T_CRIT ? i0 + u : T_CRIT - 1) * WAVE + lane]; rank[u] = 0; }
-#pragma unroll 4
+                // (k photons already inside the inner radius: the range was guessed too high -- the rigorous range never is)
+                const bool crowded = act && k_eff > 0 && (in_bin > (uint32_t)T_CRIT || crit == 0);
+                TILE_COUNT(TP_R_CROWD, crowded);
+                if (crowded) { redo = true; act = false; }
+                const bool some = act && k_eff > 0;
+                const int need = (int)(k_eff - below);                 // 1-based rank of the k-th smallest inside its bin
+                __builtin_amdgcn_wave_barrier();
+                // ---- 3b. the distances of that bin, ranked
+                int cnt;
+                if (any_radius) TILE_PROF(TP_CRIT, cnt = stream_crit<true>(pack, n_pack, qx, qy, qz, sh, radius2, some ? crit : -1));
+                else TILE_PROF(TP_CRIT, cnt = stream_crit<false>(pack, n_pack, qx, qy, qz, sh, radius2, some ? crit : -1));
+                const unsigned long long t_rank = PROF ? clock64() : 0ull;
+                const int max_cnt = (int)wave_max_f((float)cnt);
+                uint32_t t_bits = 0;
+                for (int i0 = 0; i0 < max_cnt; i0 += 8) {
+                    // eight entries in registers per sweep over the lane's column
+                    uint32_t e[8];
+                    int rank[8];
+    #pragma unroll
+                    for (int u = 0; u < 8; u++) { e[u] = cell[(i0 + u < T_CRIT ? i0 + u : T_CRIT - 1) * WAVE + lane]; rank[u] = 0; }
+    #pragma unroll 4
+                    for (int j = 0; j < max_cnt; j++) {
+                        const uint32_t o = cell[j * WAVE + lane];
+                        const bool in_col = j < cnt;
+    #pragma unroll
+                        for (int u = 0; u < 8; u++) rank[u] += (in_col && (o < e[u] || (o == e[u] && j < i0 + u))) ? 1 : 0;
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 8; u++)
+                        if (i0 + u < cnt && rank[u] == need - 1) t_bits = e[u];
+                }
+                int less = 0, equal = 0;
                 for (int j = 0; j < max_cnt; j++) {
                     const uint32_t o = cell[j * WAVE + lane];
-                    const bool in_col = j < cnt;
-#pragma unroll
-                    for (int u = 0; u < 8; u++) rank[u] += (in_col && (o < e[u] || (o == e[u] && j < i0 + u))) ? 1 : 0;
+                    less += (j < cnt && o < t_bits) ? 1 : 0;
+                    equal += (j < cnt && o == t_bits) ? 1 : 0;
                 }
-#pragma unroll
-                for (int u = 0; u < 8; u++)
-                    if (i0 + u < cnt && rank[u] == need - 1) t_bits = e[u];
-            }
-            int less = 0, equal = 0;
-            for (int j = 0; j < max_cnt; j++) {
-                const uint32_t o = cell[j * WAVE + lane];
-                less += (j < cnt && o < t_bits) ? 1 : 0;
-                equal += (j < cnt && o == t_bits) ? 1 : 0;
-            }
-            const float t_k = __uint_as_float(t_bits);             // the k-th distance = maxDistSqr (main.cpp:266-267)
-            const int want_eq = need - less;                       // photons at exactly that distance that belong to the set
-            // Several photons at exactly the k-th distance of which only some belong: the per-request kernel decides which
-            // (it has a rule that does not depend on the order the photons are met in); here every one at that distance counts.
-            const bool split_tie = some && equal != want_eq;
-            TILE_COUNT(TP_R_TIE, split_tie);
-            if (split_tie) redo = true;
-            const bool summed = some && !split_tie;
-            __builtin_amdgcn_wave_barrier();
-            if (PROF) pr[TP_RANK] += clock64() - t_rank;
-            // ---- 3c. a volume phase: the step's sums over the set (main.cpp:310-334, 346-373)
-            if (volume) {
-                VolSum vs;
-                TILE_PROF(TP_SUM, vs = stream_sum_volume(pack, n_pack, map.pos, map.aux, qx, qy, qz, t_k, summed));
-                if (summed) {
-                    // normalised by the distance from the HIT POINT to the farthest photon of the set (main.cpp:317, 353)
-                    const float dx = hx - vs.fx, dy = hy - vs.fy, dz = hz - vs.fz;
-                    const float m = dx * dx + dy * dy + dz * dz;
-                    const double scale = 1.0 / (e_pass * gp.photon_num / 8 * 3.1415926 * m * sqrtf(m));      // main.cpp:332, 371
-                    vol0 += (r.color[0] * vs.s0) * 0.2 * scale; vol1 += (r.color[1] * vs.s1) * 0.2 * scale; vol2 += (r.color[2] * vs.s2) * 0.2 * scale;
-                }
+                const float t_k = __uint_as_float(t_bits);             // the k-th distance = maxDistSqr (main.cpp:266-267)
+                const int want_eq = need - less;                       // photons at exactly that distance that belong to the set
+                // Several photons at exactly the k-th distance of which only some belong: the per-request kernel decides which
+                // (it has a rule that does not depend on the order the photons are met in); here every one at that distance counts.
+                const bool split_tie = some && equal != want_eq;
+                TILE_COUNT(TP_R_TIE, split_tie);
+                if (split_tie) redo = true;
+                const bool summed = some && !split_tie;
                 __builtin_amdgcn_wave_barrier();
-                continue;
-            }
-            // ---- 3c. the estimate over the set (main.cpp:262-295)
-            Sum3 sum;
-            {
-                const float nx = (float)r.normal[0], ny = (float)r.normal[1], nz = (float)r.normal[2];
-                const unsigned long long m_sum = __ballot(summed);
-                const int l0 = m_sum ? __builtin_ctzll(m_sum) : 0;
-                const float ax = bcast(nx, l0), ay = bcast(ny, l0), az = bcast(nz, l0);
-                if (m_sum && !__ballot(summed && (nx != ax || ny != ay || nz != az)))
-                    TILE_PROF(TP_SUM, sum = stream_sum<true>(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, ax, ay, az));
-                else
-                    TILE_PROF(TP_SUM, sum = stream_sum<false>(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, nx, ny, nz));
-            }
-            if (summed) {
-                const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
-                double rgb[3] = {r.color[0] * sum.s0 * sc, r.color[1] * sum.s1 * sc, r.color[2] * sum.s2 * sc};
-                if (SSS && sss) {
-                    surf0 = rgb[0]; surf1 = rgb[1]; surf2 = rgb[2];
-                } else {
-                    clip3(rgb);                                    // main.cpp:391
-                    for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
+                if (PROF) pr[TP_RANK] += clock64() - t_rank;
+                // ---- 3c. a volume phase: the step's sums over the set (main.cpp:310-334, 346-373)
+                if (volume) {
+                    VolSum vs;
+                    TILE_PROF(TP_SUM, vs = stream_sum_volume(pack, n_pack, map.pos, map.aux, qx, qy, qz, t_k, summed));
+                    if (summed) {
+                        // normalised by the distance from the HIT POINT to the farthest photon of the set (main.cpp:317, 353)
+                        const float dx = hx - vs.fx, dy = hy - vs.fy, dz = hz - vs.fz;
+                        const float m = dx * dx + dy * dy + dz * dz;
+                        const double scale = 1.0 / (e_pass * gp.photon_num / 8 * 3.1415926 * m * sqrtf(m));      // main.cpp:332, 371
+                        vol0 += (r.color[0] * vs.s0) * 0.2 * scale; vol1 += (r.color[1] * vs.s1) * 0.2 * scale; vol2 += (r.color[2] * vs.s2) * 0.2 * scale;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
                 }
+                // ---- 3c. the estimate over the set (main.cpp:262-295)
+                Sum3 sum;
+                {
+                    const float nx = (float)r.normal[0], ny = (float)r.normal[1], nz = (float)r.normal[2];
+                    const unsigned long long m_sum = __ballot(summed);
+                    const int l0 = m_sum ? __builtin_ctzll(m_sum) : 0;
+                    const float ax = bcast(nx, l0), ay = bcast(ny, l0), az = bcast(nz, l0);
+                    if (m_sum && !__ballot(summed && (nx != ax || ny != ay || nz != az)))
+                        TILE_PROF(TP_SUM, sum = stream_sum<true>(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, ax, ay, az));
+                    else
+                        TILE_PROF(TP_SUM, sum = stream_sum<false>(pack, n_pack, pm.aux, qx, qy, qz, t_k, summed, nx, ny, nz));
+                }
+                if (summed) {
+                    const double sc = 1.0 / (gp.norm * t_k);           // main.cpp:293
+                    double rgb[3] = {r.color[0] * sum.s0 * sc, r.color[1] * sum.s1 * sc, r.color[2] * sum.s2 * sc};
+                    if (SSS && sss) {
+                        surf0 = rgb[0]; surf1 = rgb[1]; surf2 = rgb[2];
+                    } else {
+                        clip3(rgb);                                    // main.cpp:391
+                        for (int c = 0; c < 3; c++) atomicAdd(&acc[3 * (size_t)r.pixel + c], r.weight * rgb[c]);
+                    }
+                }
+                // (a subsurface request with no surface photon in reach has a surface estimate, too: zero)
+                if (SSS && sss && act && !split_tie) sss_wait = true;
+                __builtin_amdgcn_wave_barrier();
             }
-            // (a subsurface request with no surface photon in reach has a surface estimate, too: zero)
-            if (SSS && sss && act && !split_tie) sss_wait = true;
-            __builtin_amdgcn_wave_barrier();
+            TILE_COUNT(TP_R_LEFT, todo);
+            redo = redo || todo;
+            todo = false;
         }
-        TILE_COUNT(TP_R_LEFT, todo);
-        redo = redo || todo;
-        todo = false;
-        }      // (phases)
         if (SSS && sss_wait) {
             if (volume_here && !redo) {
                 // every phase answered: surface + volume terms (main.cpp:389), clipped (main.cpp:391)
