@@ -26,8 +26,10 @@
 //
 // Same exact k-nearest set as the per-request form (rt_gather.hip.h): the search radius is exclusive in both,
 // photons at exactly the k-th distance either all belong or the request is handed on.  Requests a group cannot
-// take (other materials' terms, rounds of a few requests, a range that fails its check, a crowded bin, lists that
-// overflow) go to the hand-over list, which the per-request kernel works off.
+// take (rounds of a few requests, a range that fails its check, a crowded bin, lists that overflow) go to the
+// hand-over list, which the per-request kernel works off.  Subsurface requests (main.cpp:297-388: one gather in
+// the surface map, three in the map of photons scattered inside the material) are answered whole by the
+// subsurface instantiation of the kernel, in up to three more phases of rounds over the volume map per window.
 #pragma once
 #include "rt_gather_tile.hip.h"
 
