@@ -345,6 +345,9 @@ uint64_t tile_view_key(const rt_context* ctx, const rtk::PrimaryArgs& a, int pre
 int tile_order_of(rt_context* ctx, uint64_t key, hipEvent_t* ev0, hipEvent_t* ev1)
 {
     *ev0 = *ev1 = nullptr;
+    // (a stream under graph capture is not asked about its events, nor given timing events to record)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(ctx->stream, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) return 1;
     TileTune* t = nullptr;
     TileTune* oldest = &ctx->tile_tune[0];
     for (auto& e : ctx->tile_tune) {
