@@ -27,6 +27,7 @@
 extern "C" {
 #endif
 
+/* 2: rt_stats gained tile_strata (a caller built against version 1 passes a structure that is too small) */
 #define RT_ABI_VERSION 2
 
 typedef enum rt_status {
