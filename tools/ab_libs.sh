@@ -1,5 +1,6 @@
 #!/bin/bash
 # the headline (bench.py, 300 steps) with the library in the tree and with each ab/librt_amd_<name>.so given, twice round (scratch copy of the tree)
+# (ab/librt_amd_<name>.so: other builds of the library, e.g. `hipcc ... -DRT_SOMETHING -c rt_device.hip` linked like the Makefile does; ab/ is ignored by git)
 cd ${GRAFT_REPO_ROOT:-.}
 cp raytracer_amd/librt_amd.so /tmp/librt_amd_tree.so
 for rep in 1 2; do

@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B on the GPU box: the water frame (k = C4_K) with the library in the tree and with ab/librt_amd_old.so in its place, alternating (scratch copy of the tree)
+# (ab/librt_amd_old.so: the library built from another commit, e.g. in a `git worktree`; ab/ is ignored by git)
 cd ${GRAFT_REPO_ROOT:-.}
 cp raytracer_amd/librt_amd.so /tmp/librt_amd_new.so
 for rep in 1 2 3; do
