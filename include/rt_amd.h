@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-/* 2: rt_stats gained tile_strata (a caller built against version 1 passes a structure that is too small) */
+/* 2: rt_stats gained tile_order (a caller built against version 1 passes a structure that is too small) */
 #define RT_ABI_VERSION 2
 
 typedef enum rt_status {
@@ -102,9 +102,10 @@ typedef struct rt_stats {
     double kernel_ms;         /* device time of the call measured with HIP events on the context's stream */
     double trace_kernel_ms;   /* device time of the traversal kernel launches only */
     uint64_t gather_single;   /* of gather_queries: answered one per wave (subsurface hits, groups the grouped form handed over) */
-    uint64_t tile_strata;     /* rt_trace_primary*: the order this launch took the frame's tiles in -- 1: the plain sequence, 2: from the
-                               * frame's two halves in turn; the library measures both on the first launches of a view that repeats and
-                               * keeps the faster (same frames either way).  0 from the other entry points */
+    uint64_t tile_order;      /* rt_trace_primary*: the order this launch took the frame's tiles in -- 1: the plain sequence, 2: from the
+                               * frame's two halves in turn, 3 (single precision): two tiles per wave; the library measures them on the
+                               * first launches of a view that repeats and keeps the fastest (same frames either way).  0 from the
+                               * other entry points */
 } rt_stats;
 
 /* ---- process / context ------------------------------------------------------------------- */

@@ -39,7 +39,7 @@ class RenderParams(ctypes.Structure):
 class Stats(ctypes.Structure):
     _fields_ = [
         ("primary_rays", ctypes.c_uint64), ("secondary_rays", ctypes.c_uint64), ("shadow_rays", ctypes.c_uint64),
-        ("gather_queries", ctypes.c_uint64), ("inner_visits", ctypes.c_uint64), ("prim_tests", ctypes.c_uint64), ("kernel_ms", c_d), ("trace_kernel_ms", c_d), ("gather_single", ctypes.c_uint64), ("tile_strata", ctypes.c_uint64),
+        ("gather_queries", ctypes.c_uint64), ("inner_visits", ctypes.c_uint64), ("prim_tests", ctypes.c_uint64), ("kernel_ms", c_d), ("trace_kernel_ms", c_d), ("gather_single", ctypes.c_uint64), ("tile_order", ctypes.c_uint64),
     ]
 
 

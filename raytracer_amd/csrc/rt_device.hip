@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>      // (types and signatures only: the library is bound at run time, see rccl_load)
 #include <dlfcn.h>
+#include <type_traits>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -138,13 +139,14 @@ struct rt_scene {
 
 // The order in which the camera-ray kernel takes a frame's tiles, chosen by measurement per view (see tile_order_of): which
 // of the two orders a launch of this frame used when it was timed, how long it took, and which one has won.
-constexpr int TILE_TUNE_ENTRIES = 32, TILE_TUNE_TRIALS = 4;
+constexpr int TILE_TUNE_ENTRIES = 32, TILE_TUNE_TRIALS = 4, TILE_ORDERS = 3;
 struct TileTune {
     uint64_t key = 0;                    // of scene, camera, frame and query
-    int decided = 0;                     // 0: still measuring; else the number of strata (1 or 2)
+    int decided = 0;                     // 0: still measuring; else the order (1: plain, 2: two strata, 3: two tiles per wave)
+    int candidates = 2;                  // orders measured for this view
     int seen = 0;                        // launches of the view so far (the first is not yet a trial: a camera that moves never comes back)
-    int started = 0;                     // timed launches begun: launch i runs between ev[2 i] and ev[2 i + 1] with 1 + i % 2 strata
-    hipEvent_t ev[4 * TILE_TUNE_TRIALS] = {};
+    int started = 0;                     // timed launches begun: launch i runs between ev[2 i] and ev[2 i + 1] in order 1 + i % candidates
+    hipEvent_t ev[2 * TILE_ORDERS * TILE_TUNE_TRIALS] = {};
     uint64_t used = 0;                   // for replacement: the least recently used entry goes
 };
 
@@ -341,8 +343,9 @@ uint64_t tile_view_key(const rt_context* ctx, const rtk::PrimaryArgs& a, int pre
     return h ? h : 1;
 }
 
-// -> the strata this launch is to use; *ev0 / *ev1: the events it is to run between (null: untimed)
-int tile_order_of(rt_context* ctx, uint64_t key, hipEvent_t* ev0, hipEvent_t* ev1)
+// -> the order this launch is to use (1: plain, 2: two strata, 3: two tiles per wave); *ev0 / *ev1: the events it is to run
+// between (null: untimed).  `candidates`: the orders worth measuring for this kind of launch (the first `candidates` of them).
+int tile_order_of(rt_context* ctx, uint64_t key, int candidates, hipEvent_t* ev0, hipEvent_t* ev1)
 {
     *ev0 = *ev1 = nullptr;
     // (a stream under graph capture is not asked about its events, nor given timing events to record)
@@ -359,29 +362,34 @@ int tile_order_of(rt_context* ctx, uint64_t key, hipEvent_t* ev0, hipEvent_t* ev
         // (its events are about to be recorded anew: the launches they belong to have to be past them)
         if (!t->decided && t->started > 0 && hipEventSynchronize(t->ev[2 * t->started - 1]) != hipSuccess) return 1;
         t->key = key; t->decided = 0; t->started = 0; t->seen = 0;
+        t->candidates = std::max(2, std::min(candidates, TILE_ORDERS));
     }
     t->used = ++ctx->tile_tune_clock;
     if (t->decided) return t->decided;
     if (t->seen++ == 0) return 1;      // (a view seen once is not worth measuring: frames of a moving camera all take the plain order)
-    if (t->started < 2 * TILE_TUNE_TRIALS) {
+    const int n_timed = t->candidates * TILE_TUNE_TRIALS;
+    if (t->started < n_timed) {
         hipEvent_t& a = t->ev[2 * t->started];
         hipEvent_t& b = t->ev[2 * t->started + 1];
         if ((!a && hipEventCreate(&a) != hipSuccess) || (!b && hipEventCreate(&b) != hipSuccess)) return 1;
         *ev0 = a; *ev1 = b;
-        return 1 + (t->started++ & 1);
+        return 1 + (t->started++ % t->candidates);
     }
-    if (hipEventQuery(t->ev[4 * TILE_TUNE_TRIALS - 1]) != hipSuccess) return 1;      // (the timed launches are still under way)
-    float best[2] = {3.0e38f, 3.0e38f};
-    for (int i = 0; i < 2 * TILE_TUNE_TRIALS; i++) {
+    if (hipEventQuery(t->ev[2 * n_timed - 1]) != hipSuccess) return 1;      // (the timed launches are still under way)
+    float best[TILE_ORDERS] = {3.0e38f, 3.0e38f, 3.0e38f};
+    for (int i = 0; i < n_timed; i++) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, t->ev[2 * i], t->ev[2 * i + 1]) == hipSuccess) best[i & 1] = std::min(best[i & 1], ms);
+        if (hipEventElapsedTime(&ms, t->ev[2 * i], t->ev[2 * i + 1]) == hipSuccess) best[i % t->candidates] = std::min(best[i % t->candidates], ms);
     }
-    t->decided = best[1] < best[0] ? 2 : 1;
+    t->decided = 1;
+    for (int o = 1; o < t->candidates; o++)
+        if (best[o] < best[t->decided - 1]) t->decided = o + 1;
     return t->decided;
 }
 
+// (`two_tiles`: the kernel form in which a wave takes two tiles -- single precision, node image in LDS; plain otherwise)
 template <class R, bool COUNT, bool TRI_ONLY>
-int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow, bool want_counts)
+int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow, bool want_counts, bool two_tiles)
 {
     int cap = stack_cap(ctx);
     TraceGeom g;
@@ -395,6 +403,16 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
     if ((rc = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), g.lds))) return rc;     \
     hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, MODE>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a, \
                        d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes)
+    if constexpr (std::is_same<R, float>::value && !COUNT) {
+        if (g.mode == rtk::TRAV_NODES && two_tiles) {
+            blocks = ((blocks + rtk::N_XCD - 1) / rtk::N_XCD + 1) / 2 * rtk::N_XCD;      // (two places of an XCD's sequence per block)
+            if ((rc = allow_dynamic_lds(ctx, reinterpret_cast<const void*>(&rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, rtk::TRAV_NODES, 2>), g.lds))) return rc;
+            hipLaunchKernelGGL((rtk::trace_primary_kernel<R, COUNT, TRI_ONLY, rtk::TRAV_NODES, 2>), dim3(blocks), dim3(g.threads), g.lds, ctx->stream, view<R>(ctx), a,
+                               d_ids, d_t, d_shadow, (rtk::TraceCounters*)ctx->counters.p, cap, ctx->n_nodes);
+            HIP_TRY(hipGetLastError());
+            return RT_OK;
+        }
+    }
     if (g.mode == rtk::TRAV_NODES) { RT_LAUNCH_PRIMARY(rtk::TRAV_NODES); }
     else if (g.mode == rtk::TRAV_RETEST) { RT_LAUNCH_PRIMARY(rtk::TRAV_RETEST); }
     else { RT_LAUNCH_PRIMARY(rtk::TRAV_PLAIN); }
@@ -404,10 +422,10 @@ int launch_primary_t(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids,
 }
 
 template <class R, bool COUNT>
-int launch_primary(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow, bool want_counts)
+int launch_primary(rt_context* ctx, const rtk::PrimaryArgs& a, int32_t* d_ids, double* d_t, int32_t* d_shadow, bool want_counts, bool two_tiles)
 {
-    return view<R>(ctx).tri_only ? launch_primary_t<R, COUNT, true>(ctx, a, d_ids, d_t, d_shadow, want_counts)
-                                 : launch_primary_t<R, COUNT, false>(ctx, a, d_ids, d_t, d_shadow, want_counts);
+    return view<R>(ctx).tri_only ? launch_primary_t<R, COUNT, true>(ctx, a, d_ids, d_t, d_shadow, want_counts, two_tiles)
+                                 : launch_primary_t<R, COUNT, false>(ctx, a, d_ids, d_t, d_shadow, want_counts, two_tiles);
 }
 
 int check_params(const rt_render_params* p)
@@ -1415,16 +1433,21 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
     a.width = p->width; a.height = p->height; a.row_begin = row_begin; a.row_end = row_end;
     a.shadow = p->shadow_rays == 2 ? 2 : (p->shadow_rays ? 1 : 0);
     a.band_rows = p->band_rows; a.n_parts = p->n_parts; a.part = p->part;
+    // the order the frame's tiles are taken in: measured per view (tile_order_of) unless a switch fixes it
+    int order = 1;
     a.strata = 1;
     hipEvent_t tune_ev0 = nullptr, tune_ev1 = nullptr;
-    if (const char* e = getenv("RT_TILE_STRATA")) a.strata = std::max(1, std::min(16, atoi(e)));      // tuning aid (see tile_of_wave)
-    else if (!p->count_work) a.strata = tile_order_of(ctx, tile_view_key(ctx, a, p->precision), &tune_ev0, &tune_ev1);
+    if (const char* e = getenv("RT_TILE_STRATA")) a.strata = std::max(1, std::min(16, atoi(e)));      // tuning aids (see tile_of_wave)
+    else if (const char* e = getenv("RT_TILE_ORDER")) order = std::max(1, std::min(TILE_ORDERS, atoi(e)));
+    else if (!p->count_work) order = tile_order_of(ctx, tile_view_key(ctx, a, p->precision), p->precision == RT_F32 ? 3 : 2, &tune_ev0, &tune_ev1);
+    if (order == 2) a.strata = 2;
+    const bool two_tiles = order == 3;
     if (stats) HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));      // (timing events only for a caller that reads them)
     if (tune_ev0) HIP_TRY(hipEventRecord(tune_ev0, ctx->stream));
     if (p->count_work)
-        rc = p->precision == RT_F64 ? launch_primary<double, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr) : launch_primary<float, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr);
+        rc = p->precision == RT_F64 ? launch_primary<double, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr, false) : launch_primary<float, true>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr, false);
     else
-        rc = p->precision == RT_F64 ? launch_primary<double, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr) : launch_primary<float, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr);
+        rc = p->precision == RT_F64 ? launch_primary<double, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr, false) : launch_primary<float, false>(ctx, a, d_ids, d_t, d_shadow_ids, stats != nullptr, two_tiles);
     if (rc) return rc;
     if (tune_ev1) HIP_TRY(hipEventRecord(tune_ev1, ctx->stream));
     if (stats) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
@@ -1441,7 +1464,7 @@ int rt_trace_primary_dev(rt_context* ctx, const rt_camera* cam, const rt_render_
         HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
         stats->kernel_ms = ms;
         stats->trace_kernel_ms = ms;
-        stats->tile_strata = (uint64_t)a.strata;
+        stats->tile_order = getenv("RT_TILE_STRATA") ? (uint64_t)a.strata : (uint64_t)order;
     }
     return RT_OK;
     });

@@ -419,11 +419,11 @@ __host__ __device__ inline long long tile_grid_blocks(int tiles_x, int tiles_y, 
     return (per_xcd + waves_per_block - 1) / waves_per_block * N_XCD;
 }
 template <bool COMPACT>
-__device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, int* ty, unsigned split = 1, int* part = nullptr, unsigned strata = 1)
+__device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, int* ty, unsigned split = 1, int* part = nullptr, unsigned strata = 1, unsigned bid = blockIdx.x)
 {
     const unsigned wpb = blockDim.x >> 6;
     if (!COMPACT) {
-        const unsigned long long w = (unsigned long long)blockIdx.x * wpb + (threadIdx.x >> 6);
+        const unsigned long long w = (unsigned long long)bid * wpb + (threadIdx.x >> 6);
         const unsigned long long tile = w / split;
         if (part) *part = (int)(w % split);
         if (tile >= (unsigned long long)tiles_x * tiles_y) return false;
@@ -431,7 +431,7 @@ __device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, 
         *ty = (int)(tile / (unsigned)tiles_x);
         return true;
     }
-    const unsigned xcd = blockIdx.x % N_XCD, slot = blockIdx.x / N_XCD;
+    const unsigned xcd = bid % N_XCD, slot = bid / N_XCD;
     const unsigned long long w = (unsigned long long)slot * wpb + (threadIdx.x >> 6);
     const unsigned long long q = w / split;
     if (part) *part = (int)(w % split);
@@ -456,7 +456,11 @@ __device__ __forceinline__ bool tile_of_wave(int tiles_x, int tiles_y, int* tx, 
 // Pixel loop front end: camera ray (always generated in double, then rounded to R) + BVH::Shoot
 // with distance 1e9 (main.cpp:812-813); optional shadow ray toward the light.
 // Work unit = 8x8 pixel tile per wave.
-template <class R, bool COUNT, bool TRI_ONLY, int MODE>
+// ROUNDS = 2: a wave takes two tiles, consecutive places of its XCD's sequence, one after the other (unrolled: a loop around
+// the traversal costs some forty registers) -- half as many blocks stage the node image.  One of the orders the launch
+// code measures for a view in single precision, where it wins a few views by 8-15 % and loses most by more; in double it
+// costs a wave per SIMD (120 registers) and never won.
+template <class R, bool COUNT, bool TRI_ONLY, int MODE, int ROUNDS = 1>
 __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView<R> sv, PrimaryArgs a, int* __restrict__ ids,
                                                                   double* __restrict__ t_out, int* __restrict__ shadow_ids,
                                                                   TraceCounters* ctr, int cap, int n_nodes)
@@ -474,7 +478,9 @@ __global__ __launch_bounds__(MAX_BLOCK) void trace_primary_kernel(rtf::SceneView
     // blocks as earlier ones retire (a shared counter serves only ~90 requests per microsecond
     // chip-wide, which is fewer than the tiles this kernel retires)
     int tx, ty;
-    if (tile_of_wave<MODE == TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, 1, nullptr, (unsigned)a.strata)) {
+#pragma unroll
+    for (int round = 0; round < ROUNDS; round++)
+    if (tile_of_wave<MODE == TRAV_NODES>(tiles_x, tiles_y, &tx, &ty, 1, nullptr, (unsigned)a.strata, ROUNDS == 1 ? blockIdx.x : ((blockIdx.x / N_XCD) * ROUNDS + round) * N_XCD + blockIdx.x % N_XCD)) {
         int x = tx * 8 + (st.lane & 7), yl = ty * 8 + (st.lane >> 3);
         if (x < a.width && yl < rows) {
             int yc = a.row_begin + yl;   // row in this call's (compact) row space

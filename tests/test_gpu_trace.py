@@ -561,7 +561,7 @@ def test_tile_order_is_chosen_by_measurement_and_changes_no_frame(gpu_ctx, scene
     for fixed in ("1", "2", "4"):
         monkeypatch.setenv("RT_TILE_STRATA", fixed)
         ids, _, _, st = gpu_ctx.trace_primary(cam, plain)
-        assert st.tile_strata == int(fixed) and id_map_hash(ids) == g["hash"]
+        assert st.tile_order == int(fixed) and id_map_hash(ids) == g["hash"]
         folded = gpu_ctx.trace_primary(cam, p)[0]
         assert id_map_hash(np.where(folded >= 0, folded & ~(1 << 30), folded)) == g["hash"]
         if fixed == "1":
@@ -572,13 +572,30 @@ def test_tile_order_is_chosen_by_measurement_and_changes_no_frame(gpu_ctx, scene
     for i in range(13):      # (every call here waits for its kernel: the view's first launch, then the eight timed ones)
         folded, _, _, st = gpu_ctx.trace_primary(cam, p)
         assert eq(folded, reference)
-        seen.append(int(st.tile_strata))
+        seen.append(int(st.tile_order))
     assert seen[:9] == [1] + [1, 2] * 4 and seen[9] in (1, 2) and seen[9:] == [seen[9]] * 4
     print("tile order settled on", seen[9], "strata for the teapot frame with occlusion queries")
     # another view is measured anew, from its second launch on; the first one keeps its order; a camera that moves stays plain
     cam2 = rt.look_at((2.4, -0.8, -1.0), (0, -0.5, 0))
-    assert [int(gpu_ctx.trace_primary(cam2, p)[3].tile_strata) for _ in range(4)] == [1, 1, 2, 1]
-    assert int(gpu_ctx.trace_primary(cam, p)[3].tile_strata) == seen[9]
+    assert [int(gpu_ctx.trace_primary(cam2, p)[3].tile_order) for _ in range(4)] == [1, 1, 2, 1]
+    assert int(gpu_ctx.trace_primary(cam, p)[3].tile_order) == seen[9]
     for i in range(1, 7):
         moving = rt.look_at((2.4 + 0.01 * i, -0.8, -1.0), (0, -0.5, 0))
-        assert int(gpu_ctx.trace_primary(moving, p)[3].tile_strata) == 1
+        assert int(gpu_ctx.trace_primary(moving, p)[3].tile_order) == 1
+    # single precision has a third order to measure (two tiles per wave): the id map is the plain order's in all three
+    pf = rt.default_params(width=1920, height=1080, shadow_rays=2, precision=rt.RT_F32)
+    monkeypatch.setenv("RT_TILE_ORDER", "1")
+    ref32 = gpu_ctx.trace_primary(cam, pf)[0]
+    for fixed in ("2", "3"):
+        monkeypatch.setenv("RT_TILE_ORDER", fixed)
+        ids32, _, _, st = gpu_ctx.trace_primary(cam, pf)
+        assert st.tile_order == int(fixed) and eq(ids32, ref32)
+    monkeypatch.delenv("RT_TILE_ORDER")
+    seen32 = [int(gpu_ctx.trace_primary(cam, pf)[3].tile_order) for _ in range(15)]
+    assert seen32[:13] == [1] + [1, 2, 3] * 4 and seen32[13] in (1, 2, 3) and seen32[14] == seen32[13]
+    # (an odd frame: the two-tile form pads its grid)
+    small = rt.default_params(width=200, height=136, precision=rt.RT_F32)
+    monkeypatch.setenv("RT_TILE_ORDER", "1")
+    ref_small = gpu_ctx.trace_primary(cam, small)[0]
+    monkeypatch.setenv("RT_TILE_ORDER", "3")
+    assert eq(gpu_ctx.trace_primary(cam, small)[0], ref_small)
