@@ -37,11 +37,11 @@ def main():
         ids = torch.empty((h, w), dtype=torch.int32, device="cuda")
         for prec in (rt.RT_F64, rt.RT_F32):
             p = rt.default_params(width=w, height=h, precision=prec, shadow_rays=2)
-            # (launches two to nine of a view are the library's timed trials of its two tile orders: a synchronisation behind
+            # (launches two to thirteen of a view are the library's timed trials of its two tile orders: a synchronisation behind
             # them, so that the rest run in the order it settled on, and enough launches that the trials weigh little)
             for i in range(max(reps, 60)):
                 ctx.trace_primary_dev(CAM, p, (0, h), ids.data_ptr(), None, None, stats=False)
-                if i == 9:
+                if i == 14:
                     ctx.synchronize()
             ctx.synchronize()
         print("c2: %d launches per precision" % max(reps, 60))
